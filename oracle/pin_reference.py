@@ -1,0 +1,150 @@
+"""Pin the oracle against the UNMODIFIED reference and generate tests/golden/*.npz.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (the only place /root/reference exists):
+
+    python oracle/pin_reference.py            # checks + (re)writes tests/golden/
+
+What it does
+  1. makes the reference importable with the stub recipe of SURVEY.md §8(c) (empty modules for
+     torchvision / cv2 / skimage / models.vgg19_gray — none of them is touched on the hot path);
+  2. instantiates the reference's own VGG19_pytorch / WarpNet / ColorVidNet, loads the synthetic
+     state_dicts from dvc_amd.synth (this also proves the state_dict key contract of §8b:
+     `load_state_dict(strict=True)` must succeed);
+  3. runs reference `frame_colorization` and the oracle restatement on the same inputs and requires
+     bit-identical outputs (fp32), for each golden case;
+  4. stores inputs-by-seed + reference outputs as small fixtures.
+
+Nothing under /root/reference is copied; only its outputs on synthetic data are stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PKG = os.path.join(ROOT, "deep-exemplar-based-video-colorization_amd")
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    for name in ["torchvision", "torchvision.models", "torchvision.utils", "torchvision.transforms",
+                 "cv2", "skimage", "skimage.color", "skimage.io", "models.vgg19_gray"]:
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+    sys.modules["cv2"].setNumThreads = lambda n: None
+    sys.modules["models.vgg19_gray"].vgg19_gray = None
+    sys.modules["models.vgg19_gray"].vgg19_gray_new = None
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.modules["skimage"].color = sys.modules["skimage.color"]
+    sys.modules["skimage"].io = sys.modules["skimage.io"]
+    sys.path.insert(0, REF)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models.NonlocalNet import VGG19_pytorch, WarpNet
+        from models.ColorVidNet import ColorVidNet
+        from models.FrameColor import frame_colorization
+        import utils.util as rutil
+    sys.path.remove(REF)
+    # drop the reference's `models`/`utils` namespace packages so ours can be imported later
+    ref_mods = {k: v for k, v in sys.modules.items()
+                if k == "models" or k.startswith("models.") or k == "utils" or k.startswith("utils.")}
+    for k in ref_mods:
+        del sys.modules[k]
+    return VGG19_pytorch, WarpNet, ColorVidNet, frame_colorization, rutil
+
+
+# golden cases: (name, H, W, n_frames, temperature)
+CASES = [
+    ("small_48x80_T1e-10", 48, 80, 2, 1e-10),     # 48/16 exact, no replicate-pad branch
+    ("small_40x64_T0.01", 40, 64, 2, 0.01),        # 40/16 = 2.5 -> replicate-pad branch, soft T
+    ("full_216x384_T1e-10", 216, 384, 2, 1e-10),   # BASELINE configs[0]/[1]
+]
+
+
+def main(write=True):
+    sys.path.insert(0, PKG)
+    sys.path.insert(0, ROOT)
+    from dvc_amd import synth
+    from oracle import dvc_oracle as O
+
+    VGG19_pytorch, WarpNet, ColorVidNet, ref_frame_colorization, rutil = import_reference()
+    torch.manual_seed(0)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        vgg, warp, col = VGG19_pytorch(), WarpNet(1), ColorVidNet(7)
+    sd_v, sd_w, sd_c = synth.vgg19_state_dict(0), synth.warpnet_state_dict(0), synth.colorvidnet_state_dict(0)
+    vgg.load_state_dict(sd_v, strict=True)
+    warp.load_state_dict(sd_w, strict=True)
+    col.load_state_dict(sd_c, strict=True)
+    for m in (vgg, warp, col):
+        m.eval()
+    assert list(vgg.state_dict().keys()) == list(sd_v.keys())
+    assert set(warp.state_dict().keys()) == set(sd_w.keys())
+    assert list(col.state_dict().keys()) == list(sd_c.keys()), "ColorVidNet key order"
+    print("state_dict key contract: OK (%d + %d + %d tensors)" % (len(sd_v), len(sd_w), len(sd_c)))
+
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    for name, H, W, nf, T in CASES:
+        IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
+        frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W) for i in range(nf)]
+        with torch.no_grad():
+            # reference, exactly as test.py:61-96 drives it
+            rgb_ref = rutil.tensor_lab2rgb(torch.cat((rutil.uncenter_l(IB[:, 0:1]), IB[:, 1:3]), dim=1))
+            featB_ref = vgg(rgb_ref, ["r12", "r22", "r32", "r42", "r52"], preprocess=True)
+            last = torch.zeros_like(frames[0])
+            ref_out = []
+            for fr in frames:
+                ab, nl, fA = ref_frame_colorization(fr, IB, last, featB_ref, vgg, warp, col,
+                                                    joint_training=False, feature_noise=0, temperature=T)
+                ref_out.append((ab, nl, fA))
+                last = torch.cat((fr[:, 0:1], ab), dim=1)
+            # oracle restatement
+            rgb_or = O.tensor_lab2rgb(torch.cat((O.uncenter_l(IB[:, 0:1]), IB[:, 1:3]), dim=1))
+            featB_or = O.vgg19_forward(sd_v, rgb_or, O.VGG_OUT)
+            last = torch.zeros_like(frames[0])
+            or_out, taps = [], []
+            for fr in frames:
+                tp = {}
+                ab, nl, fA = O.frame_colorization(fr, IB, last, featB_or, sd_v, sd_w, sd_c,
+                                                  temperature=T, taps=tp)
+                or_out.append((ab, nl, fA))
+                taps.append(tp)
+                last = torch.cat((fr[:, 0:1], ab), dim=1)
+        d_rgb = (rgb_ref - rgb_or).abs().max().item()
+        assert d_rgb == 0.0, ("tensor_lab2rgb", d_rgb)
+        for i in range(nf):
+            for a, b, what in [(ref_out[i][0], or_out[i][0], "ab"), (ref_out[i][1], or_out[i][1], "warped_lab")]:
+                assert torch.equal(a, b), (name, i, what, (a - b).abs().max().item())
+            for a, b in zip(ref_out[i][2], or_out[i][2]):
+                assert torch.equal(a, b), (name, i, "features_A")
+        for a, b in zip(featB_ref, featB_or):
+            assert torch.equal(a, b), (name, "features_B")
+        print(f"{name}: oracle == reference bit-exact on ab / warped_lab / features_A "
+              f"(lab2rgb max diff {d_rgb:.1e})")
+        if write:
+            tp = taps[0]
+            np.savez_compressed(
+                os.path.join(GOLD, name + ".npz"),
+                H=H, W=W, n_frames=nf, temperature=T,
+                exemplar_rgb_sum=np.float64(rgb_ref.double().sum().item()),
+                ab=np.stack([o[0][0].numpy() for o in ref_out]),
+                warped_lab_small=np.stack([o[1][0, :, ::4, ::4].numpy() for o in ref_out]),
+                argmax0=tp["argmax"][0].numpy().astype(np.int32),
+                sim0=tp["sim_small"][0, 0].numpy(),
+                top2gap0=(tp["top2"][0, :, 0] - tp["top2"][0, :, 1]).numpy(),
+                r52_mean=np.array([o[2][4].double().mean().item() for o in ref_out]),
+                r12_absmean=np.array([o[2][0].double().abs().mean().item() for o in ref_out]),
+            )
+    print("golden fixtures written to", GOLD if write else "(dry run)")
+
+
+if __name__ == "__main__":
+    main(write="--check" not in sys.argv)
