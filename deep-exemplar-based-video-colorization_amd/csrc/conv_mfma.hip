@@ -1,0 +1,434 @@
+// Im2col-free implicit-GEMM convolution on the gfx950 fp32 matrix cores.
+//
+// GEMM view (per image n):  D[co][pix] = sum_{ci,tap} Wp[ci][tap][co] * T(x)[ci][pix shifted by tap]
+//   M = output channels  (MFMA A operand = weights,   A[i = lane&31][k = lane>>5])
+//   N = output pixels    (MFMA B operand = input,     B[k = lane>>5][j = lane&31])
+//   K = Cin * ks*ks, walked as (chunk of CK input channels) x (tap) x (2 channels per MFMA)
+// With v_mfma_f32_32x32x2_f32 the D fragment is D[row = (reg&3)+8*(reg>>2)+4*(lane>>5)][col = lane&31],
+// so lanes 0..31 of one accumulator register hold 32 consecutive pixels of ONE output channel:
+// the NCHW epilogue store is a coalesced 128-byte row segment.
+//
+// Per workgroup (4 wave64): MT = 32*WM*RM output channels x (WN*RN) N-tiles of 32 pixels.  An N-tile
+// is (32/TW) rows x TW columns, N-tiles are stacked vertically, so the block's pixel tile is
+// PH = WN*RN*32/TW rows x TW columns.  For each chunk of CK input channels the block stages
+//   xs[CK][IH_T][IW_P]  the input patch INCLUDING the halo (loaded once, reused by all ks*ks taps) with
+//                       pad / reflect / nearest-upsample / subsample folded into the index map and the
+//                       InstanceNorm affine (+PReLU) folded into the value, and
+//   ws[CK][ks*ks][MT]   the weight slice (co contiguous -> conflict-free A reads)
+// into LDS, then runs ks*ks*CK/2 MFMA steps per register tile.  fp32 MFMA is 64 cycles per
+// instruction per SIMD, so LDS bandwidth (2 ds_read_b32 per 1..4 MFMAs) is never the limiter; the
+// design goal is enough workgroups (>= 1-2 waves per SIMD) and few staged bytes per MFMA.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CONV_EPT 12  // staged input elements per thread kept as precomputed offsets
+
+struct ConvKArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* in_scale;
+    const float* in_shift;
+    const float* in_slope_ptr;
+    const float* act_slope_ptr;
+    const float* res;
+    float* y;
+    int N, Cin, H, W;   // stored input
+    int VH, VW;         // virtual input (after up/sub-sampling)
+    int Cout, OH, OW;
+    int ks, stride, dil, pad, pad_mode, in_up, in_sub;
+    int act, in_prelu;
+    float act_slope;
+    long x_bs, y_bs, res_bs;
+    int ck;             // input channels per chunk (even)
+    int IH_T, IW_T, IW_P;
+    int xs_floats;      // CK*IH_T*IW_P rounded up to a multiple of 4
+};
+
+// virtual coordinate -> stored offset component, or -1 when the tap reads a zero
+__device__ __forceinline__ int map_virtual(int v, int V, int pad_mode) {
+    if (v < 0) {
+        if (pad_mode != DVC_PAD_REFLECT) return -1;
+        v = -v;
+    } else if (v >= V) {
+        if (pad_mode != DVC_PAD_REFLECT) return -1;
+        v = 2 * (V - 1) - v;
+    }
+    return (v >= 0 && v < V) ? v : -1;  // far outside only happens for discarded partial-tile outputs
+}
+
+__device__ __forceinline__ int stored_offset(const ConvKArgs& a, int vy, int vx) {
+    int sy = map_virtual(vy, a.VH, a.pad_mode);
+    int sx = map_virtual(vx, a.VW, a.pad_mode);
+    if (sy < 0 || sx < 0) return -1;
+    if (a.in_up == 2) {
+        sy >>= 1;
+        sx >>= 1;
+    } else if (a.in_sub == 2) {
+        sy <<= 1;
+        sx <<= 1;
+    }
+    return sy * a.W + sx;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case DVC_ACT_RELU: return v > 0.f ? v : 0.f;
+        case DVC_ACT_PRELU:
+        case DVC_ACT_LEAKY: return v >= 0.f ? v : v * slope;
+        case DVC_ACT_TANH128: return tanhf(v) * 128.f;
+        default: return v;
+    }
+}
+
+template <int WM, int WN, int RM, int RN, int TW>
+__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int MT = 32 * WM * RM;
+    constexpr int RPT = 32 / TW;  // rows per 32-pixel N-tile
+    constexpr int PH = WN * RN * RPT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* ws = smem + a.xs_floats;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_x = (a.OW + TW - 1) / TW;
+    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const int ox0 = bx * TW, oy0 = by * PH;
+    const int m0 = blockIdx.y * MT;
+    const int n = blockIdx.z;
+    const int KK = a.ks * a.ks;
+    const int CK = a.ck;
+    const long HW = (long)a.H * a.W;
+    const float* xn = a.x + (long)n * a.x_bs;
+    const float* scn = a.in_scale ? a.in_scale + (long)n * a.Cin : nullptr;
+    const float* shn = a.in_shift ? a.in_shift + (long)n * a.Cin : nullptr;
+    const float in_slope = a.in_prelu ? *a.in_slope_ptr : 0.f;
+
+    const int plane = a.IH_T * a.IW_P;
+    const int tile_elems = a.IH_T * a.IW_T;
+    const int total = CK * tile_elems;
+    const int vy0 = oy0 * a.stride - a.pad, vx0 = ox0 * a.stride - a.pad;
+
+    // ---- per-thread staging plan (identical for every channel chunk)
+    const bool fast = total <= CONV_EPT * NT;
+    int goff[CONV_EPT];   // offset inside one channel plane, -1 = zero, -2 = nothing to do
+    int lpack[CONV_EPT];  // (channel-in-chunk << 24) | LDS float offset
+    if (fast) {
+#pragma unroll
+        for (int t = 0; t < CONV_EPT; ++t) {
+            int e = tid + t * NT;
+            if (e < total) {
+                int c = e / tile_elems;
+                int rem = e - c * tile_elems;
+                int iy = rem / a.IW_T;
+                int ix = rem - iy * a.IW_T;
+                goff[t] = stored_offset(a, vy0 + iy, vx0 + ix);
+                lpack[t] = (c << 24) | (c * plane + iy * a.IW_P + ix);
+            } else {
+                goff[t] = -2;
+                lpack[t] = 0;
+            }
+        }
+    }
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int boff[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        int t = wn * RN + j;
+        int r = l31 / TW, c = l31 % TW;
+        boff[j] = ((t * RPT + r) * a.stride) * a.IW_P + c * a.stride;
+    }
+    const int aoff = wm * RM * 32 + l31;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        __syncthreads();  // previous chunk's LDS reads are done
+        // ---- stage input patch
+        if (fast) {
+#pragma unroll
+            for (int t = 0; t < CONV_EPT; ++t) {
+                if (goff[t] != -2) {
+                    int c = lpack[t] >> 24;
+                    int ch = c0 + c;
+                    float v = 0.f;
+                    if (goff[t] >= 0 && ch < a.Cin) {
+                        v = xn[(long)ch * HW + goff[t]];
+                        if (scn) v = v * scn[ch] + shn[ch];
+                        if (a.in_prelu) v = v >= 0.f ? v : v * in_slope;
+                    }
+                    xs[lpack[t] & 0xFFFFFF] = v;
+                }
+            }
+        } else {
+            for (int e = tid; e < total; e += NT) {
+                int c = e / tile_elems;
+                int rem = e - c * tile_elems;
+                int iy = rem / a.IW_T;
+                int ix = rem - iy * a.IW_T;
+                int g = stored_offset(a, vy0 + iy, vx0 + ix);
+                int ch = c0 + c;
+                float v = 0.f;
+                if (g >= 0 && ch < a.Cin) {
+                    v = xn[(long)ch * HW + g];
+                    if (scn) v = v * scn[ch] + shn[ch];
+                    if (a.in_prelu) v = v >= 0.f ? v : v * in_slope;
+                }
+                xs[c * plane + iy * a.IW_P + ix] = v;
+            }
+        }
+        // ---- stage weight slice: rows (c,tap) of MT contiguous output channels
+        {
+            constexpr int ROW4 = MT / 4;
+            const int nq = CK * KK * ROW4;
+            const int grow_end = a.Cin * KK;
+            for (int q = tid; q < nq; q += NT) {
+                int row = q / ROW4;  // ROW4 is a power of two
+                int col = (q % ROW4) * 4;
+                int grow = c0 * KK + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (grow < grow_end && m0 + col < a.Cout)
+                    v = *reinterpret_cast<const float4*>(a.w + (long)grow * a.Cout + m0 + col);
+                *reinterpret_cast<float4*>(ws + row * MT + col) = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over taps x channel pairs
+        for (int tap = 0; tap < KK; ++tap) {
+            int ky = tap / a.ks, kx = tap - ky * a.ks;
+            const float* xp0 = xs + hi * plane + ky * a.dil * a.IW_P + kx * a.dil;
+            const float* wp0 = ws + (hi * KK + tap) * MT + aoff;
+#pragma unroll 4
+            for (int kk = 0; kk < CK; kk += 2) {
+                const float* xp = xp0 + kk * plane;
+                const float* wp = wp0 + kk * KK * MT;
+                float av[RM], bv[RN];
+#pragma unroll
+                for (int i = 0; i < RM; ++i) av[i] = wp[i * 32];
+#pragma unroll
+                for (int j = 0; j < RN; ++j) bv[j] = xp[boff[j]];
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias + residual + activation, coalesced NCHW store
+    const float slope = a.act_slope_ptr ? *a.act_slope_ptr : a.act_slope;
+    const long OHW = (long)a.OH * a.OW;
+    float* yn = a.y + (long)n * a.y_bs;
+    const float* rn_ = a.res ? a.res + (long)n * a.res_bs : nullptr;
+    const int pr = l31 / TW, pc = l31 % TW;
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        int t = wn * RN + j;
+        int oy = oy0 + t * RPT + pr;
+        int ox = ox0 + pc;
+        if (oy >= a.OH || ox >= a.OW) continue;
+        long pix = (long)oy * a.OW + ox;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int co = m0 + (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (co < a.Cout) {
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[co];
+                    if (rn_) v += rn_[(long)co * OHW + pix];
+                    yn[(long)co * OHW + pix] = apply_act(v, a.act, slope);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct ConvCfg {
+    int wm, wn, rm, rn;
+};
+// ordered from fewest staged bytes per MFMA (largest tile) to most workgroups (smallest tile)
+static const ConvCfg kCfgs[5] = {
+    {1, 4, 2, 2},  // 0: 64 co x 8 N-tiles
+    {1, 4, 1, 2},  // 1: 32 co x 8 N-tiles
+    {1, 4, 2, 1},  // 2: 64 co x 4 N-tiles
+    {1, 4, 1, 1},  // 3: 32 co x 4 N-tiles
+    {2, 2, 1, 1},  // 4: 64 co x 2 N-tiles
+};
+
+template <int WM, int WN, int RM, int RN>
+static void launch_tw(int tw, dim3 grid, size_t lds, hipStream_t s, const ConvKArgs& a) {
+    constexpr int NT = 64 * WM * WN;
+    switch (tw) {
+        case 32: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 32>), grid, dim3(NT), lds, s, a); break;
+        case 16: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 16>), grid, dim3(NT), lds, s, a); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 8>), grid, dim3(NT), lds, s, a); break;
+    }
+}
+
+static int virt_dim(int S, int up, int sub) {
+    if (up == 2) return S * 2;
+    if (sub == 2) return (S + 1) / 2;
+    return S;
+}
+
+extern "C" int dvc_conv2d_out_hw(const DvcConvDesc* d, int32_t* OH, int32_t* OW) {
+    DVC_REQUIRE(d, "dvc_conv2d_out_hw: null descriptor");
+    int VH = virt_dim(d->H, d->in_up, d->in_sub), VW = virt_dim(d->W, d->in_up, d->in_sub);
+    int ext = d->dil * (d->ksize - 1) + 1;
+    *OH = (VH + 2 * d->pad - ext) / d->stride + 1;
+    *OW = (VW + 2 * d->pad - ext) / d->stride + 1;
+    return 0;
+}
+
+static int pick_tw(int OW) {
+    int best = 32, best_w = cdiv(OW, 32) * 32;
+    for (int tw : {16, 8}) {
+        int wpad = cdiv(OW, tw) * tw;
+        if (wpad < best_w) {
+            best = tw;
+            best_w = wpad;
+        }
+    }
+    return best;
+}
+
+extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_packed,
+                          const float* bias, const float* in_scale, const float* in_shift,
+                          const float* in_slope_ptr, const float* act_slope_ptr,
+                          const float* residual, float* y, dvcStream stream) {
+    DVC_REQUIRE(d && x && w_packed && y, "dvc_conv2d: null argument");
+    DVC_REQUIRE(d->ksize == 1 || d->ksize == 3, "dvc_conv2d: ksize must be 1 or 3 (got %d)", d->ksize);
+    DVC_REQUIRE(d->stride == 1 || d->stride == 2, "dvc_conv2d: stride must be 1 or 2");
+    DVC_REQUIRE(d->dil == 1 || d->dil == 2, "dvc_conv2d: dilation must be 1 or 2");
+    DVC_REQUIRE(d->pad >= 0 && d->pad <= 2, "dvc_conv2d: pad must be 0..2");
+    DVC_REQUIRE(d->Cout % 4 == 0, "dvc_conv2d: Cout must be a multiple of 4 (got %d)", d->Cout);
+    DVC_REQUIRE((d->in_up == 1 || d->in_up == 2) && (d->in_sub == 1 || d->in_sub == 2) &&
+                    !(d->in_up == 2 && d->in_sub == 2),
+                "dvc_conv2d: bad in_up/in_sub");
+    DVC_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dvc_conv2d: scale/shift must come together");
+    DVC_REQUIRE(!d->in_prelu || in_slope_ptr, "dvc_conv2d: in_prelu needs in_slope_ptr");
+    DVC_REQUIRE(d->N > 0 && d->Cin > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "dvc_conv2d: bad shape");
+    DVC_REQUIRE((reinterpret_cast<uintptr_t>(w_packed) & 15) == 0, "dvc_conv2d: weights must be 16-byte aligned");
+
+    ConvKArgs a;
+    a.x = x; a.w = w_packed; a.bias = bias; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.in_slope_ptr = in_slope_ptr; a.act_slope_ptr = act_slope_ptr; a.res = residual; a.y = y;
+    a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
+    a.VH = virt_dim(d->H, d->in_up, d->in_sub);
+    a.VW = virt_dim(d->W, d->in_up, d->in_sub);
+    int32_t OH, OW;
+    dvc_conv2d_out_hw(d, &OH, &OW);
+    DVC_REQUIRE(OH > 0 && OW > 0, "dvc_conv2d: empty output");
+    if (d->pad_mode == DVC_PAD_REFLECT)
+        DVC_REQUIRE(d->pad < a.VH && d->pad < a.VW, "dvc_conv2d: reflect pad needs pad < input size");
+    a.Cout = d->Cout; a.OH = OH; a.OW = OW;
+    a.ks = d->ksize; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.pad_mode = d->pad_mode;
+    a.in_up = d->in_up; a.in_sub = d->in_sub; a.act = d->act; a.in_prelu = d->in_prelu;
+    a.act_slope = d->act_slope;
+    a.x_bs = d->x_batch_stride ? d->x_batch_stride : (long)d->Cin * d->H * d->W;
+    a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long)d->Cout * OH * OW;
+    a.res_bs = d->res_batch_stride ? d->res_batch_stride : (long)d->Cout * OH * OW;
+
+    const int tw = pick_tw(OW);
+    const int rpt = 32 / tw;
+    int cfg = d->cfg;
+    if (cfg < 0) {
+        // largest tile that still gives >= 2 waves per SIMD (2048 waves); else >= 1; else most waves
+        int first1 = -1, first2 = -1, most = 0;
+        long most_waves = -1;
+        for (int i = 0; i < 5; ++i) {
+            const ConvCfg& c = kCfgs[i];
+            int mt = 32 * c.wm * c.rm, ph = c.wn * c.rn * rpt;
+            long waves = 4L * cdiv(OW, tw) * cdiv(OH, ph) * cdiv(d->Cout, mt) * d->N;
+            if (d->Cout < mt && i != 1 && i != 3) continue;  // don't waste half the M tile
+            if (waves >= 2048 && first2 < 0) first2 = i;
+            if (waves >= 1024 && first1 < 0) first1 = i;
+            if (waves > most_waves) { most_waves = waves; most = i; }
+        }
+        cfg = first2 >= 0 ? first2 : (first1 >= 0 ? first1 : most);
+    }
+    DVC_REQUIRE(cfg >= 0 && cfg < 5, "dvc_conv2d: cfg out of range");
+    const ConvCfg& c = kCfgs[cfg];
+    const int mt = 32 * c.wm * c.rm, ph = c.wn * c.rn * rpt;
+    a.ck = d->ksize == 1 ? 32 : 8;
+    a.IH_T = (ph - 1) * d->stride + d->dil * (d->ksize - 1) + 1;
+    a.IW_T = (tw - 1) * d->stride + d->dil * (d->ksize - 1) + 1;
+    // row pitch: rows of one N-tile must land on disjoint bank ranges for ds_read_b32 (32 banks):
+    // pitch == tw (mod 32) for tw in {16, 8}; anything >= IW_T for tw == 32.
+    int pitch = a.IW_T;
+    if (tw < 32 && d->stride == 1) {
+        while (pitch % 32 != tw) ++pitch;
+    }
+    a.IW_P = pitch;
+    a.xs_floats = (a.ck * a.IH_T * a.IW_P + 3) & ~3;
+    size_t lds = sizeof(float) * ((size_t)a.xs_floats + (size_t)a.ck * a.ks * a.ks * mt);
+    DVC_REQUIRE(lds <= 160 * 1024, "dvc_conv2d: LDS tile too large (%zu bytes)", lds);
+    dim3 grid(cdiv(OW, tw) * cdiv(OH, ph), cdiv(d->Cout, mt), d->N);
+    hipStream_t s = (hipStream_t)stream;
+    switch (cfg) {
+        case 0: launch_tw<1, 4, 2, 2>(tw, grid, lds, s, a); break;
+        case 1: launch_tw<1, 4, 1, 2>(tw, grid, lds, s, a); break;
+        case 2: launch_tw<1, 4, 2, 1>(tw, grid, lds, s, a); break;
+        case 3: launch_tw<1, 4, 1, 1>(tw, grid, lds, s, a); break;
+        default: launch_tw<2, 2, 1, 1>(tw, grid, lds, s, a); break;
+    }
+    DVC_CHECK_LAUNCH("dvc_conv2d");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 conv with Cout <= 4 (ColorVidNet.conv10_ab: 128 -> 2, then tanh*128).  Bandwidth-trivial:
+// one thread per pixel, channel loop with coalesced reads along the pixel axis.
+template <int COUT>
+__global__ void conv1x1_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                     const float* __restrict__ bias, int Cin, long HW, int act,
+                                     float* __restrict__ y) {
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int n = blockIdx.y;
+    if (p >= HW) return;
+    const float* xn = x + (long)n * Cin * HW + p;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+    for (int c = 0; c < Cin; ++c) {
+        float v = xn[(long)c * HW];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = fmaf(v, w[o * Cin + c], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+        float v = acc[o] + (bias ? bias[o] : 0.f);
+        y[((long)n * COUT + o) * HW + p] = apply_act(v, act, 0.f);
+    }
+}
+
+extern "C" int dvc_conv1x1_small(const float* x, const float* w, const float* bias, int32_t N,
+                                 int32_t Cin, int32_t HW, int32_t Cout, int32_t act, float* y,
+                                 dvcStream stream) {
+    DVC_REQUIRE(x && w && y, "dvc_conv1x1_small: null argument");
+    DVC_REQUIRE(Cout >= 1 && Cout <= 4, "dvc_conv1x1_small: Cout must be 1..4");
+    dim3 grid(cdiv(HW, 256), N);
+    hipStream_t s = (hipStream_t)stream;
+    switch (Cout) {
+        case 1: hipLaunchKernelGGL(conv1x1_small_kernel<1>, grid, dim3(256), 0, s, x, w, bias, Cin, (long)HW, act, y); break;
+        case 2: hipLaunchKernelGGL(conv1x1_small_kernel<2>, grid, dim3(256), 0, s, x, w, bias, Cin, (long)HW, act, y); break;
+        case 3: hipLaunchKernelGGL(conv1x1_small_kernel<3>, grid, dim3(256), 0, s, x, w, bias, Cin, (long)HW, act, y); break;
+        default: hipLaunchKernelGGL(conv1x1_small_kernel<4>, grid, dim3(256), 0, s, x, w, bias, Cin, (long)HW, act, y); break;
+    }
+    DVC_CHECK_LAUNCH("dvc_conv1x1_small");
+    return 0;
+}

@@ -1,0 +1,266 @@
+// Bandwidth-bound helpers around the conv engine: InstanceNorm statistics / apply, pooling,
+// nearest upsampling and the channel L2 normalisation.  All are deterministic (no atomics):
+// reductions are wave shuffles + one LDS hop, so repeated runs are bit-identical.
+#include "common.h"
+
+thread_local char g_dvc_err[512] = {0};
+char* dvc_err_buf() { return g_dvc_err; }
+
+extern "C" int dvc_abi_version(void) { return DVC_ABI_VERSION; }
+extern "C" const char* dvc_last_error(void) { return g_dvc_err; }
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block-wide sum of doubles (256 threads = 4 waves); result broadcast to all threads
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = wave_sum_d(v);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm statistics: one workgroup per (n,c) plane; two passes (mean, then centred sum of
+// squares) with fp64 accumulation — the plane (<= 332 KB) stays in L2 between the passes.
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __restrict__ x, int C, int HW,
+                                                             long x_bs, float eps,
+                                                             const float* __restrict__ chan_scale,
+                                                             float* __restrict__ scale,
+                                                             float* __restrict__ shift) {
+    __shared__ double red[4];
+    const int p = blockIdx.x;  // n*C + c
+    const int n = p / C, c = p - n * C;
+    const float* xp = x + (long)n * x_bs + (long)c * HW;
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    const int HW4 = ((reinterpret_cast<uintptr_t>(xp) & 15) == 0) ? (HW & ~3) : 0;
+    for (int i = tid * 4; i < HW4; i += 1024) {
+        float4 v = *reinterpret_cast<const float4*>(xp + i);
+        s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    }
+    for (int i = HW4 + tid; i < HW; i += 256) s += (double)xp[i];
+    const double mean = block_sum_d(s, red) / (double)HW;
+    double q = 0.0;
+    for (int i = tid * 4; i < HW4; i += 1024) {
+        float4 v = *reinterpret_cast<const float4*>(xp + i);
+        double a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+        q += a * a + b * b + cc * cc + d * d;
+    }
+    for (int i = HW4 + tid; i < HW; i += 256) {
+        double a = xp[i] - mean;
+        q += a * a;
+    }
+    const double var = block_sum_d(q, red) / (double)HW;
+    if (tid == 0) {
+        double rstd = 1.0 / sqrt(var + (double)eps);
+        double sc = rstd * (chan_scale ? (double)chan_scale[c] : 1.0);
+        scale[p] = (float)sc;
+        shift[p] = (float)(-mean * sc);
+    }
+}
+
+extern "C" int dvc_instnorm_stats(const float* x, int32_t N, int32_t C, int32_t HW,
+                                  int64_t x_batch_stride, float eps, const float* chan_scale,
+                                  float* scale, float* shift, dvcStream stream) {
+    DVC_REQUIRE(x && scale && shift && N > 0 && C > 0 && HW > 0, "dvc_instnorm_stats: bad argument");
+    long bs = x_batch_stride ? x_batch_stride : (long)C * HW;
+    hipLaunchKernelGGL(instnorm_stats_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream, x, C, HW,
+                       bs, eps, chan_scale, scale, shift);
+    DVC_CHECK_LAUNCH("dvc_instnorm_stats");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = prelu(x*scale + shift + residual), with optional nearest upsample and replicated row pad.
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ res,
+                                                         const float* __restrict__ slope_ptr, int C,
+                                                         int H, int W, int up, int rpad, long x_bs,
+                                                         long res_bs, long y_bs, float* __restrict__ y) {
+    const int OW = W * up, OH = H * up + 2 * rpad;
+    const int p = blockIdx.y;  // n*C + c
+    const int n = p / C, c = p - n * C;
+    const float sc = scale ? scale[p] : 1.f, sh = shift ? shift[p] : 0.f;
+    const bool has_act = slope_ptr != nullptr;
+    const float slope = has_act ? *slope_ptr : 1.f;
+    const float* xp = x + (long)n * x_bs + (long)c * H * W;
+    const float* rp = res ? res + (long)n * res_bs + (long)c * H * W : nullptr;
+    float* yp = y + (long)n * y_bs + (long)c * OH * OW;
+    const int total = OH * OW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int oy = i / OW, ox = i - oy * OW;
+        int uy = oy - rpad;
+        uy = uy < 0 ? 0 : (uy >= H * up ? H * up - 1 : uy);
+        int sy = up == 1 ? uy : uy / up, sx = up == 1 ? ox : ox / up;
+        float v = xp[sy * W + sx] * sc + sh;
+        if (rp) v += rp[sy * W + sx];
+        if (has_act) v = v >= 0.f ? v : v * slope;
+        yp[i] = v;
+    }
+}
+
+extern "C" int dvc_affine_act(const float* x, const float* scale, const float* shift,
+                              const float* residual, const float* slope_ptr, int32_t N, int32_t C,
+                              int32_t H, int32_t W, int32_t up, int32_t rpad, int64_t x_batch_stride,
+                              int64_t res_batch_stride, int64_t y_batch_stride, float* y,
+                              dvcStream stream) {
+    DVC_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0, "dvc_affine_act: bad argument");
+    DVC_REQUIRE(up >= 1 && up <= 4 && rpad >= 0, "dvc_affine_act: bad up/rpad");
+    DVC_REQUIRE(!(residual && up != 1), "dvc_affine_act: residual requires up == 1");
+    long OH = (long)H * up + 2 * rpad, OW = (long)W * up;
+    long xbs = x_batch_stride ? x_batch_stride : (long)C * H * W;
+    long rbs = res_batch_stride ? res_batch_stride : (long)C * H * W;
+    long ybs = y_batch_stride ? y_batch_stride : (long)C * OH * OW;
+    int bx = (int)((OH * OW + 1023) / 1024);
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(affine_act_kernel, dim3(bx, N * C), dim3(256), 0, (hipStream_t)stream, x, scale,
+                       shift, residual, slope_ptr, C, H, W, up, rpad, xbs, rbs, ybs, y);
+    DVC_CHECK_LAUNCH("dvc_affine_act");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict__ x, int H, int W,
+                                                         int OH, int OW, float* __restrict__ y) {
+    const float* xp = x + (long)blockIdx.y * H * W;
+    float* yp = y + (long)blockIdx.y * OH * OW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < OH * OW; i += gridDim.x * 256) {
+        int oy = i / OW, ox = i - oy * OW;
+        const float* r0 = xp + (2 * oy) * W + 2 * ox;
+        float2 a = *reinterpret_cast<const float2*>(r0);      // W even or ox<OW keeps this in range
+        float2 b = *reinterpret_cast<const float2*>(r0 + W);
+        yp[i] = fmaxf(fmaxf(a.x, a.y), fmaxf(b.x, b.y));
+    }
+}
+__global__ __launch_bounds__(256) void maxpool2x2_scalar_kernel(const float* __restrict__ x, int H, int W,
+                                                                int OH, int OW, float* __restrict__ y) {
+    const float* xp = x + (long)blockIdx.y * H * W;
+    float* yp = y + (long)blockIdx.y * OH * OW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < OH * OW; i += gridDim.x * 256) {
+        int oy = i / OW, ox = i - oy * OW;
+        const float* r0 = xp + (2 * oy) * W + 2 * ox;
+        yp[i] = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[W], r0[W + 1]));
+    }
+}
+
+extern "C" int dvc_maxpool2x2(const float* x, int32_t planes, int32_t H, int32_t W, float* y,
+                              dvcStream stream) {
+    DVC_REQUIRE(x && y && planes > 0 && H >= 2 && W >= 2, "dvc_maxpool2x2: bad argument");
+    int OH = H / 2, OW = W / 2;
+    dim3 grid(cdiv(OH * OW, 1024) > 0 ? cdiv(OH * OW, 1024) : 1, planes);
+    bool vec = (W % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7) == 0) && ((H * W) % 2 == 0);
+    if (vec)
+        hipLaunchKernelGGL(maxpool2x2_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, OH, OW, y);
+    else
+        hipLaunchKernelGGL(maxpool2x2_scalar_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, OH, OW, y);
+    DVC_CHECK_LAUNCH("dvc_maxpool2x2");
+    return 0;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, int H, int W, int OH,
+                                                      int OW, float* __restrict__ y) {
+    const float* xp = x + (long)blockIdx.y * H * W;
+    float* yp = y + (long)blockIdx.y * OH * OW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < OH * OW; i += gridDim.x * 256) {
+        int oy = i / OW, ox = i - oy * OW;
+        const float* r0 = xp + (K * oy) * W + K * ox;
+        float s = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) s += r0[dy * W + dx];
+        yp[i] = s * (1.f / (K * K));
+    }
+}
+
+extern "C" int dvc_avgpool4x4(const float* x, int32_t planes, int32_t H, int32_t W, float* y,
+                              dvcStream stream) {
+    DVC_REQUIRE(x && y && planes > 0 && H >= 4 && W >= 4, "dvc_avgpool4x4: bad argument");
+    int OH = H / 4, OW = W / 4;
+    dim3 grid(cdiv(OH * OW, 256), planes);
+    hipLaunchKernelGGL(avgpool_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, OH, OW, y);
+    DVC_CHECK_LAUNCH("dvc_avgpool4x4");
+    return 0;
+}
+
+extern "C" int dvc_avgpool2x2(const float* x, int32_t planes, int32_t H, int32_t W, float* y,
+                              dvcStream stream) {
+    DVC_REQUIRE(x && y && planes > 0 && H >= 2 && W >= 2, "dvc_avgpool2x2: bad argument");
+    int OH = H / 2, OW = W / 2;
+    dim3 grid(cdiv(OH * OW, 256), planes);
+    hipLaunchKernelGGL(avgpool_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, OH, OW, y);
+    DVC_CHECK_LAUNCH("dvc_avgpool2x2");
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void upsample_nearest_kernel(const float* __restrict__ x, int H, int W,
+                                                               int f, float* __restrict__ y) {
+    const int OH = H * f, OW = W * f;
+    const float* xp = x + (long)blockIdx.y * H * W;
+    float* yp = y + (long)blockIdx.y * OH * OW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < OH * OW; i += gridDim.x * 256) {
+        int oy = i / OW, ox = i - oy * OW;
+        yp[i] = xp[(oy / f) * W + ox / f];
+    }
+}
+
+extern "C" int dvc_upsample_nearest(const float* x, int32_t planes, int32_t H, int32_t W, int32_t f,
+                                    float* y, dvcStream stream) {
+    DVC_REQUIRE(x && y && planes > 0 && H > 0 && W > 0 && f >= 1, "dvc_upsample_nearest: bad argument");
+    dim3 grid(cdiv(H * f * W * f, 1024) > 0 ? cdiv(H * f * W * f, 1024) : 1, planes);
+    hipLaunchKernelGGL(upsample_nearest_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, f, y);
+    DVC_CHECK_LAUNCH("dvc_upsample_nearest");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// feature_normalize: per pixel, divide by the L2 norm over channels.  Workgroup = 64 pixels x 4
+// channel groups; pixel axis is the contiguous one so every load/store is a 256-byte row.
+__global__ __launch_bounds__(256) void channel_l2norm_kernel(const float* __restrict__ x, int C, long HW,
+                                                             float eps, float* __restrict__ y) {
+    __shared__ float part[4][64];
+    const int px = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long p = (long)blockIdx.x * 64 + px;
+    const int n = blockIdx.y;
+    const float* xn = x + (long)n * C * HW;
+    float* yn = y + (long)n * C * HW;
+    const bool ok = p < HW;
+    float s = 0.f;
+    if (ok)
+        for (int c = g; c < C; c += 4) {
+            float v = xn[(long)c * HW + p];
+            s = fmaf(v, v, s);
+        }
+    part[g][px] = s;
+    __syncthreads();
+    float tot = part[0][px] + part[1][px] + part[2][px] + part[3][px];
+    float den = sqrtf(tot) + eps;
+    if (ok)
+        for (int c = g; c < C; c += 4) yn[(long)c * HW + p] = xn[(long)c * HW + p] / den;
+}
+
+extern "C" int dvc_channel_l2norm(const float* x, int32_t N, int32_t C, int32_t HW, float eps, float* y,
+                                  dvcStream stream) {
+    DVC_REQUIRE(x && y && N > 0 && C > 0 && HW > 0, "dvc_channel_l2norm: bad argument");
+    dim3 grid(cdiv(HW, 64), N);
+    hipLaunchKernelGGL(channel_l2norm_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, C, (long)HW, eps, y);
+    DVC_CHECK_LAUNCH("dvc_channel_l2norm");
+    return 0;
+}

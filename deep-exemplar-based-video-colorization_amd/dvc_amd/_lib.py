@@ -1,0 +1,81 @@
+"""ctypes binding of libdvc_hip.so (the C-ABI declared in include/dvc_hip.h).
+
+There is deliberately NO CPU / eager-PyTorch fallback: if the shared library is missing or an input
+is not a ROCm device tensor, the call raises.  (The CPU restatement lives in oracle/ and is test
+infrastructure only.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdvc_hip.so")
+ABI_VERSION = 1
+
+c_float_p = ctypes.c_void_p
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+
+
+class DvcConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", c_i32), ("Cin", c_i32), ("H", c_i32), ("W", c_i32),
+        ("Cout", c_i32), ("ksize", c_i32), ("stride", c_i32), ("dil", c_i32),
+        ("pad", c_i32), ("pad_mode", c_i32), ("in_up", c_i32), ("in_sub", c_i32),
+        ("act", c_i32), ("act_slope", ctypes.c_float), ("in_prelu", c_i32), ("cfg", c_i32),
+        ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("res_batch_stride", c_i64),
+    ]
+
+
+# every symbol include/dvc_hip.h declares: name -> (restype, argtypes)
+_VP = ctypes.c_void_p
+SIGNATURES = {
+    "dvc_abi_version": (ctypes.c_int, []),
+    "dvc_last_error": (ctypes.c_char_p, []),
+    "dvc_conv2d_out_hw": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "dvc_conv2d": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "dvc_conv1x1_small": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, _VP, _VP]),
+    "dvc_instnorm_stats": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, c_i64, ctypes.c_float, _VP, _VP, _VP, _VP]),
+    "dvc_affine_act": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                      c_i64, c_i64, c_i64, _VP, _VP]),
+    "dvc_maxpool2x2": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),
+    "dvc_avgpool2x2": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),
+    "dvc_avgpool4x4": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),
+    "dvc_upsample_nearest": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, c_i32, _VP, _VP]),
+    "dvc_channel_l2norm": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP]),
+    "dvc_gray2rgb": (ctypes.c_int, [_VP, c_i32, c_i32, c_i64, _VP, _VP]),
+    "dvc_lab2rgb": (ctypes.c_int, [_VP, c_i32, c_i32, ctypes.c_float, _VP, _VP]),
+    "dvc_pack_color_input": (ctypes.c_int, [_VP, _VP, _VP, _VP, c_i32, c_i32, _VP, _VP]),
+    "dvc_corr_prepare": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP]),
+    "dvc_corr_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
+    "dvc_corr_fwd": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_float, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,
+                                    _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_size_t, _VP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdvc_hip.so (once) and attach the signatures.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (or `make -C csrc`). "
+            "There is no CPU fallback for the HIP path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == symbol missing from the .so
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.dvc_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libdvc_hip.so ABI version {got} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().dvc_last_error().decode(errors="replace")
+        raise RuntimeError(f"libdvc_hip {what} failed: {msg}")

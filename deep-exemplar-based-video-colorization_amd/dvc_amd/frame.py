@@ -1,0 +1,104 @@
+"""Frame orchestration: drop-in `warp_color` / `frame_colorization`
+(/root/reference/models/FrameColor.py:5-38, 41-67) plus an exemplar-cached clip driver.
+"""
+import torch
+
+from . import ops
+from .util import feature_normalize, gray2rgb_batch
+
+VGG_OUT = ["r12", "r22", "r32", "r42", "r52"]
+
+
+def warp_color(IA_l, IB_lab, features_B, vggnet, nonlocal_net, colornet, feature_noise=0, temperature=0.01,
+               exemplar_cache=None):
+    """models/FrameColor.py:5-38.  `colornet` and `feature_noise` are unused there as well."""
+    IA_rgb_from_gray = gray2rgb_batch(IA_l)
+    A_relu1_1, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1 = vggnet(IA_rgb_from_gray, VGG_OUT, preprocess=True)
+    if exemplar_cache is None:
+        B_relu1_1, B_relu2_1, B_relu3_1, B_relu4_1, B_relu5_1 = features_B
+    # NOTE: output the feature before normalization (FrameColor.py:13-14)
+    features_A = [A_relu1_1, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1]
+    nA = [feature_normalize(t) for t in features_A[1:]]
+    if exemplar_cache is None:
+        nB = [feature_normalize(t) for t in (B_relu2_1, B_relu3_1, B_relu4_1, B_relu5_1)]
+        nonlocal_BA_lab, similarity_map = nonlocal_net(IB_lab, *nA, *nB, temperature=temperature)
+    else:
+        # exemplar side cached: the B feature arguments are not read (pass the A ones as placeholders)
+        nonlocal_BA_lab, similarity_map = nonlocal_net(IB_lab, *nA, *nA, temperature=temperature,
+                                                       exemplar_cache=exemplar_cache)
+    return nonlocal_BA_lab, similarity_map, features_A
+
+
+def frame_colorization(IA_lab, IB_lab, IA_last_lab, features_B, vggnet, nonlocal_net, colornet,
+                       joint_training=True, feature_noise=0, luminance_noise=0, temperature=0.01,
+                       exemplar_cache=None):
+    """models/FrameColor.py:41-67.  Returns (IA_ab_predict, nonlocal_BA_lab, features_A_gray).
+
+    `joint_training` only toggles autograd in the reference; this implementation is inference-only
+    and its outputs never carry autograd history."""
+    IA_lab = IA_lab.detach().contiguous().float()
+    IA_l = IA_lab[:, 0:1, :, :]
+    if luminance_noise:
+        IA_l = IA_l + torch.randn_like(IA_l, requires_grad=False) * luminance_noise
+        IA_lab_in = torch.cat((IA_l, IA_lab[:, 1:3]), dim=1).contiguous()
+    else:
+        IA_lab_in = IA_lab
+    nonlocal_BA_lab, similarity_map, features_A_gray = warp_color(
+        IA_l, IB_lab, features_B, vggnet, nonlocal_net, colornet, feature_noise, temperature=temperature,
+        exemplar_cache=exemplar_cache)
+    # cat((IA_l, nonlocal_BA_ab, similarity_map, IA_last_lab), dim=1)  (FrameColor.py:63-64)
+    color_input = ops.pack_color_input(IA_lab_in, nonlocal_BA_lab, similarity_map,
+                                       IA_last_lab.detach().contiguous().float())
+    IA_ab_predict = colornet(color_input)
+    return IA_ab_predict, nonlocal_BA_lab, features_A_gray
+
+
+class ClipColorizer:
+    """Per-clip driver around `frame_colorization` (the hot loop of /root/reference/test.py:57-96):
+    the exemplar's VGG features and its whole WarpNet side (heads, trunk, phi, pooled Lab) are computed
+    once per clip instead of once per frame — identical results, 52.6 GFLOP/frame less work
+    (SURVEY.md §3.1 "Redundancy")."""
+
+    def __init__(self, vggnet, nonlocal_net, colornet, temperature=1e-10, cache_exemplar=True):
+        self.vgg, self.warp, self.col = vggnet, nonlocal_net, colornet
+        self.temperature = temperature
+        self.cache_exemplar = cache_exemplar
+        self.IB_lab = None
+        self.features_B = None
+        self.ex_cache = None
+
+    def set_exemplar(self, IB_lab):
+        """test.py:61-66: Lab -> RGB -> VGG features of the reference image."""
+        IB_lab = IB_lab.detach().contiguous().float()
+        self.IB_lab = IB_lab
+        rgb = ops.lab2rgb(IB_lab, l_offset=50.0)   # uncenter_l folded into the kernel
+        self.features_B = self.vgg(rgb, VGG_OUT, preprocess=True)
+        self.ex_cache = None
+        if self.cache_exemplar:
+            nB = [feature_normalize(t) for t in self.features_B[1:]]
+            self.ex_cache = self.warp.exemplar_side(IB_lab, *nB)
+        return self.features_B
+
+    def exemplar_cache_shapes(self, lab_shape):
+        """Shapes of (phi, pooled Lab) for an exemplar of `lab_shape` (used by parallel.broadcast_exemplar)."""
+        n, _, H, W = lab_shape
+        h, w = int(H / 4), int(W / 4)
+        return [(n, 256, h * w), (n, 3, h, w)]
+
+    def frame(self, IA_lab, IA_last_lab):
+        ab, nl, _ = frame_colorization(IA_lab, self.IB_lab, IA_last_lab, self.features_B, self.vgg, self.warp,
+                                       self.col, joint_training=False, feature_noise=0,
+                                       temperature=self.temperature, exemplar_cache=self.ex_cache)
+        return ab, nl
+
+    def clip(self, frames_lab, frame_propagate=False):
+        """Recurrence of test.py:68-96; returns the list of ab predictions."""
+        last = None
+        outs = []
+        for IA_lab in frames_lab:
+            if last is None:
+                last = self.IB_lab if frame_propagate else torch.zeros_like(IA_lab)
+            ab, _ = self.frame(IA_lab, last)
+            last = torch.cat((IA_lab[:, 0:1], ab), dim=1)   # test.py:96 (pure data movement)
+            outs.append(ab)
+        return outs

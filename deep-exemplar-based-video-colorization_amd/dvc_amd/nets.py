@@ -1,0 +1,323 @@
+"""Drop-in nn.Module classes for the hot path, backed by the HIP kernels.
+
+Same constructor arguments, forward signatures, return conventions and state_dict keys as
+  VGG19_pytorch  /root/reference/models/NonlocalNet.py:192-256
+  WarpNet        /root/reference/models/NonlocalNet.py:355-502
+  ColorVidNet    /root/reference/models/ColorVidNet.py:6-144
+so `load_state_dict(torch.load(...))`, `.parameters()`, `.eval()`, `.cuda()` behave as in
+/root/reference/test.py:147-166.  The torch.nn submodules created here are *parameter containers
+only* (they give the parameters their reference names); no torch.nn forward is ever called — every
+forward pass is a sequence of libdvc_hip.so kernel launches on the current stream.
+
+Inference only: outputs never carry autograd history (the reference's training path,
+train.py:402-427, is out of scope — SURVEY.md §2 rows 12-13).
+"""
+import torch
+import torch.nn as nn
+
+from . import arch, ops
+
+_VGG_MEAN_BGR = (0.40760392, 0.45795686, 0.48501961)  # utils/util.py:351
+
+
+class _PackCache:
+    """Repacked weights ([Cin][k*k][Cout]) keyed by parameter identity + version, so an in-place
+    `load_state_dict` or a `.cuda()` move is picked up on the next forward."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, key, param, fn):
+        tag = (param.data_ptr(), param._version, str(param.device))
+        hit = self._d.get(key)
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                hit = (tag, fn(param))
+            self._d[key] = hit
+        return hit[1]
+
+
+def _check_input(x, name):
+    if not x.is_cuda:
+        raise RuntimeError(f"{name}: input is on {x.device}; the MI355X HIP path has no CPU fallback "
+                           "(move the module and its inputs to the GPU with .cuda())")
+
+
+# ================================================================================================ VGG19
+class VGG19_pytorch(nn.Module):
+    """NOTE: input tensor should range in [0,1] (RGB); see NonlocalNet.py:193-195."""
+
+    def __init__(self, pool="max"):
+        super().__init__()
+        for name, cin, cout in arch.VGG_CONVS:
+            setattr(self, name, nn.Conv2d(cin, cout, kernel_size=3, padding=1))
+        if pool not in ("max", "avg"):
+            raise ValueError("pool must be 'max' or 'avg'")
+        self._pool = pool
+        self._cache = _PackCache()
+
+    def _packed(self, name, swap_bgr=False):
+        conv = getattr(self, name)
+        if swap_bgr:  # fold RGB->BGR of vgg_preprocess into conv1_1's input-channel order
+            return self._cache.get(name + ":bgr", conv.weight, lambda w: ops.pack_conv_weight(w.flip(1)))
+        return self._cache.get(name, conv.weight, ops.pack_conv_weight)
+
+    def forward(self, x, out_keys, preprocess=True):
+        _check_input(x, "VGG19_pytorch")
+        x = x.detach().contiguous().float()
+        N = x.shape[0]
+        for k in out_keys:
+            if k not in arch.VGG_KEYS:
+                raise KeyError(k)
+        last = max(arch.VGG_KEYS.index(k) for k in out_keys) if out_keys else -1
+        out = {}
+        cur = x
+        conv_names = {("r%s" % n[4:].replace("_", "")): n for n, _, _ in arch.VGG_CONVS}
+        for i, key in enumerate(arch.VGG_KEYS):
+            if i > last:
+                break  # the reference always runs through p5; the requested outputs are identical
+            if key[0] == "p":
+                cur = ops.maxpool2x2(cur) if self._pool == "max" else ops.avgpool2x2(cur)
+            else:
+                name = conv_names[key]
+                conv = getattr(self, name)
+                bias = conv.bias.detach()
+                if name == "conv1_1" and preprocess:
+                    # vgg_preprocess (utils/util.py:347-352) folded into the load: stored channel c is
+                    # R,G,B; BGR channel c' = 2-c gets (x - mean[c'])*255 = x*255 - 255*mean[c'].
+                    sc = self._cache.get("pre:scale", conv.weight,
+                                         lambda w: torch.full((3,), 255.0, device=w.device))
+                    sh = self._cache.get("pre:shift", conv.weight, lambda w: torch.tensor(
+                        [-255.0 * _VGG_MEAN_BGR[2], -255.0 * _VGG_MEAN_BGR[1], -255.0 * _VGG_MEAN_BGR[0]],
+                        device=w.device))
+                    cur = ops.conv2d(cur, self._packed(name, swap_bgr=True), bias, act=ops.ACT_RELU,
+                                     in_scale=sc.repeat(N), in_shift=sh.repeat(N))
+                else:
+                    cur = ops.conv2d(cur, self._packed(name), bias, act=ops.ACT_RELU)
+            out[key] = cur
+        return [out[key] for key in out_keys]
+
+
+# ============================================================================================== WarpNet
+class _ResidualBlockParams(nn.Module):
+    """Parameter container with the reference's names (conv1, conv2, prelu), NonlocalNet.py:330-339."""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.conv1 = nn.Conv2d(ch, ch, kernel_size=3, padding=0, stride=1)
+        self.conv2 = nn.Conv2d(ch, ch, kernel_size=3, padding=0, stride=1)
+        self.prelu = nn.PReLU()
+
+
+def _head_container(spec):
+    n = max(max(ci, pi) for (ci, _, _, _, pi) in spec["convs"]) + 1
+    if spec["up_out"]:
+        n += 1
+    mods = [nn.Identity() for _ in range(n)]
+    for (ci, cin, cout, stride, pi) in spec["convs"]:
+        mods[ci] = nn.Conv2d(cin, cout, kernel_size=3, padding=0, stride=stride)
+        mods[pi] = nn.PReLU()
+    return nn.Sequential(*mods)
+
+
+class WarpNet(nn.Module):
+    """ input is Al, Bl, channel = 1, range~[0,255] (docstring of NonlocalNet.py:356) """
+
+    def __init__(self, batch_size):
+        super().__init__()
+        self.feature_channel = arch.WARP_FEATURE_CH
+        self.in_channels = self.feature_channel * 4
+        self.inter_channels = arch.WARP_TRUNK_CH
+        for name in arch.WARP_HEAD_ORDER:
+            setattr(self, name, _head_container(arch.WARP_HEADS[name]))
+        self.layer = nn.Sequential(*[_ResidualBlockParams(arch.WARP_TRUNK_CH)
+                                     for _ in range(arch.WARP_NUM_RESBLOCKS)])
+        self.theta = nn.Conv2d(self.in_channels, self.inter_channels, kernel_size=1, stride=1, padding=0)
+        self.phi = nn.Conv2d(self.in_channels, self.inter_channels, kernel_size=1, stride=1, padding=0)
+        self._cache = _PackCache()
+
+    # -- helpers
+    def _pk(self, key, conv):
+        return self._cache.get(key, conv.weight, ops.pack_conv_weight)
+
+    def features(self, r2, r3, r4, r5):
+        """Heads + concat + residual trunk for one side (NonlocalNet.py:451-465) -> [N,256,h,w]."""
+        feats = [r2, r3, r4, r5]
+        N = r2.shape[0]
+        dev = r2.device
+        # geometry of the four head outputs
+        shapes = []
+        for name, x in zip(arch.WARP_HEAD_ORDER, feats):
+            spec = arch.WARP_HEADS[name]
+            H, W = x.shape[2], x.shape[3]
+            if spec["up_mid"]:
+                H, W = 2 * H, 2 * W
+            s = spec["convs"][1][3]
+            H, W = (H - 1) // s + 1, (W - 1) // s + 1
+            if spec["up_out"]:
+                H, W = 2 * H, 2 * W
+            shapes.append((H, W))
+        h, w = shapes[0]
+        rpad5 = 0
+        if shapes[3] != shapes[0]:  # NonlocalNet.py:461-463 pads one replicated row top and bottom
+            rpad5 = 1
+            shapes[3] = (shapes[3][0] + 2, shapes[3][1])
+        for nm, sh in zip(arch.WARP_HEAD_ORDER, shapes):
+            if sh != (h, w):
+                raise RuntimeError(f"Sizes of tensors must match except in dimension 1: {nm} gives {sh}, "
+                                   f"layer2_1 gives {(h, w)}")
+        trunk = torch.empty((N, arch.WARP_TRUNK_CH, h, w), device=dev, dtype=torch.float32)
+        bs = arch.WARP_TRUNK_CH * h * w
+        for i, (name, x) in enumerate(zip(arch.WARP_HEAD_ORDER, feats)):
+            spec = arch.WARP_HEADS[name]
+            seq = getattr(self, name)
+            (ia, _, _, _, pa), (ib, _, _, sb, pb) = spec["convs"]
+            ca, cb = seq[ia], seq[ib]
+            t = ops.conv2d(x, self._pk(f"{name}.{ia}", ca), ca.bias.detach(), pad_mode=ops.PAD_REFLECT)
+            sc, sh = ops.instnorm_stats(t)
+            t = ops.conv2d(t, self._pk(f"{name}.{ib}", cb), cb.bias.detach(), stride=sb,
+                           pad_mode=ops.PAD_REFLECT, in_up=2 if spec["up_mid"] else 1,
+                           in_scale=sc, in_shift=sh, in_slope_t=seq[pa].weight.detach())
+            sc, sh = ops.instnorm_stats(t)
+            dst = trunk[:, i * arch.WARP_FEATURE_CH:(i + 1) * arch.WARP_FEATURE_CH]
+            ops.affine_act(t, sc, sh, slope_t=seq[pb].weight.detach(), up=2 if spec["up_out"] else 1,
+                           rpad=rpad5 if name == "layer5_1" else 0, out=dst, out_batch_stride=bs)
+        x = trunk
+        for b in range(arch.WARP_NUM_RESBLOCKS):
+            blk = self.layer[b]
+            a = blk.prelu.weight.detach()
+            t = ops.conv2d(x, self._pk(f"layer.{b}.conv1", blk.conv1), blk.conv1.bias.detach(),
+                           pad_mode=ops.PAD_REFLECT)
+            sc, sh = ops.instnorm_stats(t)
+            t = ops.conv2d(t, self._pk(f"layer.{b}.conv2", blk.conv2), blk.conv2.bias.detach(),
+                           pad_mode=ops.PAD_REFLECT, in_scale=sc, in_shift=sh, in_slope_t=a)
+            sc, sh = ops.instnorm_stats(t)
+            x = ops.affine_act(t, sc, sh, residual=x, slope_t=a)
+        return x
+
+    def project(self, which, feats):
+        """theta / phi: 1x1 conv, centre over positions, L2-normalise over channels -> [N,256,P]."""
+        conv = getattr(self, which)
+        t = ops.conv2d(feats, self._pk(which, conv), conv.bias.detach(), ksize=1, pad=0)
+        return ops.corr_prepare(t)
+
+    def exemplar_side(self, B_lab_map, B2, B3, B4, B5):
+        """Everything that depends only on the exemplar (recomputed per frame by the reference,
+        NonlocalNet.py:452-465,473-476,491-493; cacheable per clip)."""
+        phi = self.project("phi", self.features(B2, B3, B4, B5))
+        blab = ops.avgpool4x4(B_lab_map)
+        return phi, blab
+
+    def forward(self, B_lab_map, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1, B_relu2_1, B_relu3_1,
+                B_relu4_1, B_relu5_1, temperature=0.001 * 5, detach_flag=False, WTA_scale_weight=1,
+                feature_noise=0, exemplar_cache=None, return_taps=False):
+        ins = [B_lab_map, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1, B_relu2_1, B_relu3_1, B_relu4_1,
+               B_relu5_1]
+        for t in ins:
+            _check_input(t, "WarpNet")
+        ins = [t.detach().contiguous().float() for t in ins]
+        B_lab_map, A2, A3, A4, A5, B2, B3, B4, B5 = ins
+        image_height, image_width = B_lab_map.shape[2], B_lab_map.shape[3]
+        fh, fw = int(image_height / 4), int(image_width / 4)
+        A_features = self.features(A2, A3, A4, A5)
+        if (A_features.shape[2], A_features.shape[3]) != (fh, fw):
+            raise RuntimeError(f"shape '[{B_lab_map.shape[0]}, 1, {fh}, {fw}]' is invalid for feature map "
+                               f"of size {tuple(A_features.shape[2:])}")
+        theta = self.project("theta", A_features)
+        if exemplar_cache is not None:
+            phi, blab = exemplar_cache
+        else:
+            phi, blab = self.exemplar_side(B_lab_map, B2, B3, B4, B5)
+        res = ops.corr_fwd(theta, phi, blab.view(blab.shape[0], 3, -1), float(temperature), fh, fw,
+                           wta_scale=float(WTA_scale_weight), want_small=return_taps,
+                           want_argmax=return_taps)
+        if return_taps:
+            return res["y_up"], res["sim_up"], dict(theta=theta, phi=phi, y_small=res["y_small"],
+                                                    sim_small=res["sim_small"], argmax=res["argmax"],
+                                                    A_features=A_features)
+        return res["y_up"], res["sim_up"]
+
+
+# ========================================================================================== ColorVidNet
+class ColorVidNet(nn.Module):
+    def __init__(self, ic):
+        super().__init__()
+        shapes = arch.colorvidnet_param_shapes(ic)
+        made = {}
+        for key, kind in arch.CVN_STATE_ORDER:
+            w = shapes[key + ".weight"]
+            if kind == "ss":
+                mod = nn.Conv2d(w[0], w[0], 1, 2, bias=False, groups=w[0])
+            else:
+                k = w[2]
+                mod = nn.Conv2d(w[1], w[0], k, 1, 0)
+            made[key] = mod
+        # group "a.b" keys into Sequential containers so that state_dict keys match the reference
+        groups = {}
+        for key, mod in made.items():
+            if "." in key:
+                top, idx = key.split(".")
+                groups.setdefault(top, {})[int(idx)] = mod
+            else:
+                setattr(self, key, mod)
+        for top, items in groups.items():
+            seq = [nn.Identity() for _ in range(max(items) + 1)]
+            for i, m in items.items():
+                seq[i] = m
+            setattr(self, top, nn.Sequential(*seq))
+        # keep the reference's registration order (ColorVidNet.py:9-47) for state_dict()
+        order = []
+        for key, _ in arch.CVN_STATE_ORDER:
+            top = key.split(".")[0]
+            if top not in order:
+                order.append(top)
+        self._modules = type(self._modules)((k, self._modules[k]) for k in order)
+        self._ic = ic
+        self._cache = _PackCache()
+        # the reference constructor prints these two lines (ColorVidNet.py:80,85)
+        print("replace all deconv with [nearest + conv]")
+        print("replace all batchnorm with instancenorm")
+
+    def _mod(self, key):
+        m = self
+        for part in key.split("."):
+            m = m[int(part)] if part.isdigit() else getattr(m, part)
+        return m
+
+    def forward(self, x):
+        """ x: gray image (1 channel), ab(2 channel), ab_err, ba_err"""
+        _check_input(x, "ColorVidNet")
+        x = x.detach().contiguous().float()
+        acts = {"x": x}
+        stats = {}
+
+        def norm_of(src, ss_key=None):
+            k = (src, ss_key)
+            if k not in stats:
+                cs = None
+                if ss_key is not None:
+                    ssw = self._mod(ss_key).weight
+                    cs = self._cache.get(ss_key, ssw, lambda w: w.detach().reshape(-1).contiguous())
+                stats[k] = ops.instnorm_stats(acts[src], eps=1e-5, chan_scale=cs)
+            return stats[k]
+
+        act_map = {"relu": ops.ACT_RELU, "none": ops.ACT_NONE, "leaky": ops.ACT_LEAKY}
+        for c in arch.CVN_CONVS:
+            conv = self._mod(c["key"])
+            wp = self._cache.get(c["key"], conv.weight, ops.pack_conv_weight)
+            kw = dict(dil=c["dil"], pad=c["dil"], act=act_map[c["act"]], act_slope=0.2)
+            pre = c["pre"]
+            if pre == "norm":
+                kw["in_scale"], kw["in_shift"] = norm_of(c["src"])
+            elif pre == "norm_ss":
+                kw["in_scale"], kw["in_shift"] = norm_of(c["src"], c["ss"])
+                kw["in_sub"] = 2
+            elif pre == "up":
+                kw["in_scale"], kw["in_shift"] = norm_of(c["src"])
+                kw["in_up"] = 2
+            if c["add"] is not None:
+                kw["residual"] = acts[c["add"]]
+            acts[c["dst"]] = ops.conv2d(acts[c["src"]], wp, conv.bias.detach(), **kw)
+        out = self._mod(arch.CVN_OUT["key"])
+        w2 = self._cache.get("conv10_ab", out.weight, lambda w: w.detach().reshape(w.shape[0], -1).contiguous())
+        return ops.conv1x1_small(acts["c10_2"], w2, out.bias.detach(), act=ops.ACT_TANH128)

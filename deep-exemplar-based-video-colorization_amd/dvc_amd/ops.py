@@ -1,0 +1,245 @@
+"""Tensor-level wrappers over the C-ABI (include/dvc_hip.h).
+
+PyTorch is used here only for device memory (torch.empty on the caching allocator) and for the
+current HIP stream; every number is produced by the kernels in csrc/.  All functions require
+contiguous fp32 ROCm tensors and raise otherwise — there is no CPU fallback.
+"""
+import ctypes
+import sys
+
+import torch
+
+from . import _lib
+from ._lib import DvcConvDesc
+
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY, ACT_TANH128 = 0, 1, 2, 3, 4
+PAD_ZERO, PAD_REFLECT = 0, 1
+EPS64 = sys.float_info.epsilon  # the reference adds float64 epsilon to fp32 norms (util.py:156)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t, name):
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"dvc_amd: `{name}` must be a ROCm device tensor; the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"dvc_amd: `{name}` must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"dvc_amd: `{name}` must be contiguous")
+
+
+def pack_conv_weight(w):
+    """[Cout][Cin][kh][kw] -> [Cin][kh*kw][Cout] (layout consumed by dvc_conv2d).  Pure data movement."""
+    co, ci, kh, kw = w.shape
+    return w.detach().permute(1, 2, 3, 0).reshape(ci, kh * kw, co).contiguous()
+
+
+def conv_out_hw(H, W, ksize=3, stride=1, dil=1, pad=1, in_up=1, in_sub=1):
+    vh = H * 2 if in_up == 2 else ((H + 1) // 2 if in_sub == 2 else H)
+    vw = W * 2 if in_up == 2 else ((W + 1) // 2 if in_sub == 2 else W)
+    ext = dil * (ksize - 1) + 1
+    return (vh + 2 * pad - ext) // stride + 1, (vw + 2 * pad - ext) // stride + 1
+
+
+def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1,
+           act=ACT_NONE, act_slope=0.0, act_slope_t=None, in_scale=None, in_shift=None, in_slope_t=None,
+           residual=None, out=None, out_batch_stride=0, cfg=-1):
+    """dvc_conv2d.  x: [N,Cin,H,W]; w_packed: [Cin, k*k, Cout].  `out` may be a channel slice view's
+    base pointer tensor (pass `out_batch_stride` in elements)."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (w_packed, "w_packed"), (bias, "bias"), (in_scale, "in_scale"),
+                  (in_shift, "in_shift"), (in_slope_t, "in_slope"), (act_slope_t, "act_slope"),
+                  (residual, "residual")):
+        _need(t, nm)
+    N, Cin, H, W = x.shape
+    assert w_packed.shape[0] == Cin and w_packed.shape[1] == ksize * ksize, (w_packed.shape, Cin, ksize)
+    Cout = w_packed.shape[2]
+    OH, OW = conv_out_hw(H, W, ksize, stride, dil, pad, in_up, in_sub)
+    if out is None:
+        out = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
+    d = DvcConvDesc(N, Cin, H, W, Cout, ksize, stride, dil, pad, pad_mode, in_up, in_sub, act,
+                    float(act_slope), 1 if in_slope_t is not None else 0, cfg, 0, out_batch_stride, 0)
+    if residual is not None:
+        assert tuple(residual.shape) == (N, Cout, OH, OW), (residual.shape, (N, Cout, OH, OW))
+    rc = lib.dvc_conv2d(ctypes.byref(d), _p(x), _p(w_packed), _p(bias), _p(in_scale), _p(in_shift),
+                        _p(in_slope_t), _p(act_slope_t), _p(residual), _p(out), _stream())
+    _lib.check(rc, "dvc_conv2d")
+    return out
+
+
+def conv1x1_small(x, w, bias, act=ACT_NONE):
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (w, "w"), (bias, "bias")):
+        _need(t, nm)
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(lib.dvc_conv1x1_small(_p(x), _p(w), _p(bias), N, Cin, H * W, Cout, act, _p(y), _stream()),
+               "dvc_conv1x1_small")
+    return y
+
+
+def instnorm_stats(x, eps=1e-5, chan_scale=None):
+    """Returns (scale, shift), each [N*C], such that InstanceNorm(x) == x*scale + shift per plane."""
+    lib = _lib.load()
+    _need(x, "x")
+    _need(chan_scale, "chan_scale")
+    N, C, H, W = x.shape
+    scale = torch.empty(N * C, device=x.device, dtype=torch.float32)
+    shift = torch.empty(N * C, device=x.device, dtype=torch.float32)
+    _lib.check(lib.dvc_instnorm_stats(_p(x), N, C, H * W, 0, float(eps), _p(chan_scale), _p(scale), _p(shift),
+                                      _stream()), "dvc_instnorm_stats")
+    return scale, shift
+
+
+def affine_act(x, scale, shift, *, residual=None, slope_t=None, up=1, rpad=0, out=None, out_batch_stride=0):
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (scale, "scale"), (shift, "shift"), (residual, "residual"), (slope_t, "slope")):
+        _need(t, nm)
+    N, C, H, W = x.shape
+    if out is None:
+        out = torch.empty((N, C, H * up + 2 * rpad, W * up), device=x.device, dtype=torch.float32)
+    _lib.check(lib.dvc_affine_act(_p(x), _p(scale), _p(shift), _p(residual), _p(slope_t), N, C, H, W, up, rpad,
+                                  0, 0, out_batch_stride, _p(out), _stream()), "dvc_affine_act")
+    return out
+
+
+def _pool(fn_name, x, k):
+    lib = _lib.load()
+    _need(x, "x")
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H // k, W // k), device=x.device, dtype=torch.float32)
+    _lib.check(getattr(lib, fn_name)(_p(x), N * C, H, W, _p(y), _stream()), fn_name)
+    return y
+
+
+def maxpool2x2(x):
+    return _pool("dvc_maxpool2x2", x, 2)
+
+
+def avgpool2x2(x):
+    return _pool("dvc_avgpool2x2", x, 2)
+
+
+def avgpool4x4(x):
+    return _pool("dvc_avgpool4x4", x, 4)
+
+
+def upsample_nearest(x, f):
+    lib = _lib.load()
+    _need(x, "x")
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H * f, W * f), device=x.device, dtype=torch.float32)
+    _lib.check(lib.dvc_upsample_nearest(_p(x), N * C, H, W, f, _p(y), _stream()), "dvc_upsample_nearest")
+    return y
+
+
+def channel_l2norm(x, eps=EPS64):
+    lib = _lib.load()
+    _need(x, "x")
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    _lib.check(lib.dvc_channel_l2norm(_p(x), N, C, H * W, float(eps), _p(y), _stream()), "dvc_channel_l2norm")
+    return y
+
+
+def gray2rgb(l):
+    """l: [N,1,H,W] (may be the channel-0 slice of a contiguous [N,3,H,W] Lab tensor)."""
+    lib = _lib.load()
+    if not (isinstance(l, torch.Tensor) and l.is_cuda and l.dtype == torch.float32):
+        raise RuntimeError("dvc_amd: `l` must be a float32 ROCm device tensor; no CPU fallback")
+    N, C, H, W = l.shape
+    assert C == 1
+    if l.stride(3) != 1 or l.stride(2) != W:
+        l = l.contiguous()
+    bs = l.stride(0) if N > 1 else H * W
+    y = torch.empty((N, 3, H, W), device=l.device, dtype=torch.float32)
+    _lib.check(lib.dvc_gray2rgb(_p(l), N, H * W, bs, _p(y), _stream()), "dvc_gray2rgb")
+    return y
+
+
+def lab2rgb(lab, l_offset=0.0):
+    lib = _lib.load()
+    _need(lab, "lab")
+    N, C, H, W = lab.shape
+    assert C == 3
+    y = torch.empty_like(lab)
+    _lib.check(lib.dvc_lab2rgb(_p(lab), N, H * W, float(l_offset), _p(y), _stream()), "dvc_lab2rgb")
+    return y
+
+
+def pack_color_input(IA_lab, warped_lab, sim, IA_last_lab):
+    lib = _lib.load()
+    for t, nm in ((IA_lab, "IA_lab"), (warped_lab, "warped_lab"), (sim, "sim"), (IA_last_lab, "IA_last_lab")):
+        _need(t, nm)
+    N, _, H, W = IA_lab.shape
+    y = torch.empty((N, 7, H, W), device=IA_lab.device, dtype=torch.float32)
+    _lib.check(lib.dvc_pack_color_input(_p(IA_lab), _p(warped_lab), _p(sim), _p(IA_last_lab), N, H * W, _p(y),
+                                        _stream()), "dvc_pack_color_input")
+    return y
+
+
+def corr_prepare(t_raw, eps=EPS64):
+    """t_raw: [B,C,h,w] or [B,C,P] output of the theta/phi 1x1 conv -> centred + normalised [B,C,P]."""
+    lib = _lib.load()
+    _need(t_raw, "t_raw")
+    B, C = t_raw.shape[0], t_raw.shape[1]
+    P = t_raw[0, 0].numel()
+    out = torch.empty((B, C, P), device=t_raw.device, dtype=torch.float32)
+    mean = torch.empty(B * C, device=t_raw.device, dtype=torch.float32)
+    _lib.check(lib.dvc_corr_prepare(_p(t_raw), B, C, P, float(eps), _p(mean), _p(out), _stream()),
+               "dvc_corr_prepare")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        _ws_cache[key] = ws
+    return ws
+
+
+def corr_fwd(theta, phi, blab, temperature, h, w, wta_scale=1.0, want_small=False, want_argmax=False,
+             want_up=True):
+    """Fused affinity + softmax + colour gather.  theta/phi: [B,256,P]; blab: [B,3,P] (P = h*w).
+    Returns dict with y_up [B,3,4h,4w], sim_up [B,1,4h,4w] and optionally y_small / sim_small / argmax."""
+    lib = _lib.load()
+    for t, nm in ((theta, "theta"), (phi, "phi"), (blab, "blab")):
+        _need(t, nm)
+    B, C, P = theta.shape
+    assert P == h * w and tuple(phi.shape) == (B, C, P) and blab.shape[0] == B and blab[0].numel() == 3 * P
+    if not (temperature > 0):
+        raise ValueError("temperature must be > 0")
+    dev = theta.device
+    out = {}
+    y_up = sim_up = y_small = sim_small = amax = None
+    if want_up:
+        y_up = torch.empty((B, 3, 4 * h, 4 * w), device=dev, dtype=torch.float32)
+        sim_up = torch.empty((B, 1, 4 * h, 4 * w), device=dev, dtype=torch.float32)
+    if want_small:
+        y_small = torch.empty((B, 3, h, w), device=dev, dtype=torch.float32)
+        sim_small = torch.empty((B, 1, h, w), device=dev, dtype=torch.float32)
+    if want_argmax:
+        amax = torch.empty((B, P), device=dev, dtype=torch.int32)
+    nbytes = lib.dvc_corr_workspace_bytes(B, P)
+    ws = _workspace(dev, nbytes)
+    rc = lib.dvc_corr_fwd(_p(theta), _p(phi), _p(blab), float(temperature), float(wta_scale), B, C, h, w,
+                          _p(y_small), _p(sim_small), _p(y_up), _p(sim_up),
+                          None if amax is None else ctypes.c_void_p(amax.data_ptr()),
+                          ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    _lib.check(rc, "dvc_corr_fwd")
+    out.update(y_up=y_up, sim_up=sim_up, y_small=y_small, sim_small=sim_small, argmax=amax)
+    return out

@@ -1,0 +1,170 @@
+/*
+ * dvc_hip.h — C-ABI of libdvc_hip.so: hand-written gfx950 (MI355X / CDNA4) HIP kernels for the
+ * inference hot path of Deep-Exemplar-based-Video-Colorization
+ *   VGG19 features -> WarpNet dense exemplar<->frame correlation -> ColorVidNet generator.
+ *
+ * The reference (/root/reference) has NO native / FFI layer: every op on this path is a stock ATen
+ * op reached through torch.nn.  The drop-in boundary is therefore the Python module
+ * surface that /root/reference/test.py:17-19 imports; this header is the thin native layer underneath
+ * it, and each entry point cites the reference call site(s) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C: raw device pointers (fp32, NCHW, contiguous unless a batch stride is given), sizes,
+ *     and a hipStream_t passed as void*.  No torch types.  No allocation, no synchronisation: every
+ *     call only enqueues kernels on `stream` (so a caller may capture calls into a hipGraph).
+ *   - return 0 on success; non-zero on error, with a message retrievable via dvc_last_error().
+ *   - scratch memory is supplied by the caller (sizes via the *_workspace_bytes helpers).
+ */
+#ifndef DVC_HIP_H
+#define DVC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dvcStream; /* hipStream_t */
+
+#define DVC_ABI_VERSION 1
+
+int dvc_abi_version(void);
+/* Thread-local description of the last failure (empty string if none). */
+const char* dvc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution engine: im2col-free implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).
+ * Replaces every nn.Conv2d (+ the padding / upsample / norm / activation modules wrapped around it):
+ *   VGG19_pytorch.forward            models/NonlocalNet.py:235-254  (conv3x3 p1 + ReLU)
+ *   WarpNet heads / ResidualBlock    models/NonlocalNet.py:364-410, 341-352
+ *                                    (ReflectionPad2d + conv3x3 s1/s2; IN+PReLU folded into the
+ *                                     consumer's load; Upsample folded into the index map)
+ *   WarpNet.theta / .phi             models/NonlocalNet.py:418-423  (1x1)
+ *   ColorVidNet.forward              models/ColorVidNet.py:98-141   (conv3x3 d1/d2, InstanceNorm and
+ *                                     the depthwise stride-2 `*_ss` scale folded into the load,
+ *                                     nearest-up folded into the index map, skip-add + ReLU epilogue)
+ *
+ * y[n,co,oy,ox] = act( bias[co] + residual[n,co,oy,ox]
+ *                      + sum_{ci,ky,kx} w[co,ci,ky,kx] * T(x)[n,ci, oy*stride+ky*dil-pad, ox*stride+kx*dil-pad] )
+ * where T(x) is the *virtual* input: the stored tensor x[N,Cin,H,W], optionally subsampled
+ * (x[:, :, ::2, ::2]) or nearest-upsampled x2, with the per-(n,ci) affine v*in_scale+in_shift and an
+ * optional PReLU applied to in-bounds values; out-of-bounds taps read 0 (zero pad) or the mirrored
+ * position (reflect pad, applied in the virtual domain exactly like ReflectionPad2d after Upsample).
+ *
+ * Weights are pre-packed as w_packed[ci][ky*ks+kx][co] (co contiguous), Cout % 4 == 0.
+ */
+enum { DVC_ACT_NONE = 0, DVC_ACT_RELU = 1, DVC_ACT_PRELU = 2, DVC_ACT_LEAKY = 3, DVC_ACT_TANH128 = 4 };
+enum { DVC_PAD_ZERO = 0, DVC_PAD_REFLECT = 1 };
+
+typedef struct DvcConvDesc {
+    int32_t N, Cin, H, W;       /* stored input tensor */
+    int32_t Cout;
+    int32_t ksize;              /* 1 or 3 */
+    int32_t stride;             /* 1 or 2 */
+    int32_t dil;                /* 1 or 2 */
+    int32_t pad;                /* 0..2 */
+    int32_t pad_mode;           /* DVC_PAD_* */
+    int32_t in_up;              /* 1 | 2 : nearest upsample of the stored input */
+    int32_t in_sub;             /* 1 | 2 : keep every 2nd row/col of the stored input */
+    int32_t act;                /* DVC_ACT_* */
+    float   act_slope;          /* PReLU/LeakyReLU slope when act_slope_ptr == NULL */
+    int32_t in_prelu;           /* apply PReLU (slope *in_slope_ptr) to the affine-transformed input */
+    int32_t cfg;                /* tile configuration; -1 = choose automatically */
+    int64_t x_batch_stride;     /* elements; 0 => Cin*H*W */
+    int64_t y_batch_stride;     /* elements; 0 => Cout*OH*OW  (lets y be a channel slice) */
+    int64_t res_batch_stride;   /* elements; 0 => Cout*OH*OW */
+} DvcConvDesc;
+
+/* Output spatial size implied by a descriptor. */
+int dvc_conv2d_out_hw(const DvcConvDesc* d, int32_t* OH, int32_t* OW);
+
+int dvc_conv2d(const DvcConvDesc* d,
+               const float* x, const float* w_packed, const float* bias /* may be NULL */,
+               const float* in_scale /* [N*Cin] or NULL */, const float* in_shift /* [N*Cin] or NULL */,
+               const float* in_slope_ptr /* device scalar, used when in_prelu */,
+               const float* act_slope_ptr /* device scalar or NULL */,
+               const float* residual /* or NULL */, float* y, dvcStream stream);
+
+/* conv 1x1 with tiny Cout (<= 4) + optional tanh*128: ColorVidNet.conv10_ab, ColorVidNet.py:142-144.
+ * w is the unpacked [Cout][Cin] matrix. */
+int dvc_conv1x1_small(const float* x, const float* w, const float* bias, int32_t N, int32_t Cin,
+                      int32_t HW, int32_t Cout, int32_t act, float* y, dvcStream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * InstanceNorm2d (eps, no affine, biased variance), split as "statistics" + "apply":
+ *   models/NonlocalNet.py:335,339,368,...   models/ColorVidNet.py:85-94
+ * stats: for every plane p=(n,c) of HW elements computes mean/var (fp64 accumulation, like ATen's CPU
+ *   batch-norm statistics) and writes scale[p] = rstd * (chan_scale ? chan_scale[c] : 1),
+ *   shift[p] = -mean * scale[p].  chan_scale carries the depthwise `*_ss` weights (ColorVidNet.py:12).
+ */
+int dvc_instnorm_stats(const float* x, int32_t N, int32_t C, int32_t HW, int64_t x_batch_stride,
+                       float eps, const float* chan_scale, float* scale, float* shift,
+                       dvcStream stream);
+
+/* apply: y = prelu_or_id( x*scale + shift + residual ), optional nearest x`up` upsample and `rpad`
+ * replicated rows on top and bottom (F.pad(...,(0,0,1,1),'replicate'), NonlocalNet.py:461-463).
+ * slope_ptr == NULL => no activation.  y is [N][C][(H*up)+2*rpad][W*up] with its own batch stride. */
+int dvc_affine_act(const float* x, const float* scale, const float* shift, const float* residual,
+                   const float* slope_ptr, int32_t N, int32_t C, int32_t H, int32_t W, int32_t up,
+                   int32_t rpad, int64_t x_batch_stride, int64_t res_batch_stride,
+                   int64_t y_batch_stride, float* y, dvcStream stream);
+
+/* nn.MaxPool2d(2,2) floor mode, NonlocalNet.py:237-255. planes = N*C. */
+int dvc_maxpool2x2(const float* x, int32_t planes, int32_t H, int32_t W, float* y, dvcStream stream);
+/* nn.AvgPool2d(2,2): the pool="avg" variant of VGG19_pytorch, NonlocalNet.py:221-226. */
+int dvc_avgpool2x2(const float* x, int32_t planes, int32_t H, int32_t W, float* y, dvcStream stream);
+/* F.avg_pool2d(x, 4), NonlocalNet.py:491. */
+int dvc_avgpool4x4(const float* x, int32_t planes, int32_t H, int32_t W, float* y, dvcStream stream);
+/* nn.Upsample(scale_factor=f) nearest, NonlocalNet.py:425,499-500. */
+int dvc_upsample_nearest(const float* x, int32_t planes, int32_t H, int32_t W, int32_t f, float* y,
+                         dvcStream stream);
+/* feature_normalize: x / (||x||_2 over C + eps), utils/util.py:155-158. */
+int dvc_channel_l2norm(const float* x, int32_t N, int32_t C, int32_t HW, float eps, float* y,
+                       dvcStream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Colour / glue elementwise ops.
+ */
+/* gray2rgb_batch (utils/util.py:97-101): y[n,0..2] = (L+50)/100. */
+int dvc_gray2rgb(const float* l, int32_t N, int32_t HW, int64_t l_batch_stride, float* y,
+                 dvcStream stream);
+/* tensor_lab2rgb (utils/util.py:379-414): Lab (L in [0,100], i.e. already uncentred when
+ * l_offset == 0; pass l_offset = 50 to fold uncenter_l, utils/util.py:63-64) -> sRGB [0,1]. */
+int dvc_lab2rgb(const float* lab, int32_t N, int32_t HW, float l_offset, float* rgb,
+                dvcStream stream);
+/* cat((IA_l, nonlocal_BA_lab[:,1:3], similarity_map, IA_last_lab), 1): models/FrameColor.py:63-64. */
+int dvc_pack_color_input(const float* IA_lab, const float* warped_lab, const float* sim,
+                         const float* IA_last_lab, int32_t N, int32_t HW, float* out7,
+                         dvcStream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense correlation (the north-star kernel).  Replaces models/NonlocalNet.py:469-500:
+ *   centre + normalise theta/phi -> f = theta^T phi (P x P) -> similarity = rowmax f ->
+ *   softmax(f / T) -> y = softmax @ avgpool4(B_lab) -> nearest x4 upsample of y and similarity.
+ * The P x P affinity is never written to memory: query rows live in registers, exemplar ("key")
+ * tiles stream through LDS, the 256-deep dot products run on v_mfma_f32_32x32x2_f32, and the row
+ * softmax is an online (running max / running sum) recurrence kept per lane.
+ */
+/* t_raw[B][C][P] (output of the 1x1 theta/phi conv) -> t[b,c,p] = (t_raw - mean_p) / (||.||_C + eps)
+ * mean_scratch: B*C floats. */
+int dvc_corr_prepare(const float* t_raw, int32_t B, int32_t C, int32_t P, float eps,
+                     float* mean_scratch, float* t_out, dvcStream stream);
+
+size_t dvc_corr_workspace_bytes(int32_t B, int32_t P);
+
+/* theta, phi: [B][C][P] centred+normalised (C must be 256).  blab: [B][3][P] pooled exemplar Lab.
+ * temperature > 0.  wta_scale == 1 disables the winner-take-all rescale (NonlocalNet.py:486);
+ * otherwise f' = (f == rowmax f) ? f : f * wta_scale (WTA_scale.forward, NonlocalNet.py:295-309).
+ * Outputs (any may be NULL): y_small [B][3][h][w], sim_small [B][1][h][w] with h*w == P,
+ * y_up [B][3][4h][4w], sim_up [B][1][4h][4w], argmax [B][P] (index of the largest affinity per row,
+ * lowest index on exact ties). */
+int dvc_corr_fwd(const float* theta, const float* phi, const float* blab, float temperature,
+                 float wta_scale, int32_t B, int32_t C, int32_t h, int32_t w, float* y_small,
+                 float* sim_small, float* y_up, float* sim_up, int32_t* argmax, void* workspace,
+                 size_t workspace_bytes, dvcStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVC_HIP_H */

@@ -1,0 +1,103 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dvc_hip.h declares (no compute calls
+without a GPU), host-side logic (weight packing, geometry, state_dict contract, loud failures)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "dvc_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dvc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dvc_amd import _lib
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in dvc_hip.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert lib.dvc_abi_version() == _lib.ABI_VERSION
+    assert lib.dvc_corr_workspace_bytes(1, 5184) > 0
+
+
+def test_argument_validation_without_gpu():
+    """Validation errors are reported through the return code + dvc_last_error, before any launch."""
+    from dvc_amd import _lib
+    lib = _lib.load()
+    d = _lib.DvcConvDesc(1, 4, 8, 8, 6, 3, 1, 1, 1, 0, 1, 1, 0, 0.0, 0, -1, 0, 0, 0)   # Cout % 4 != 0
+    one = ctypes.c_void_p(16)
+    rc = lib.dvc_conv2d(ctypes.byref(d), one, one, None, None, None, None, None, None, one, None)
+    assert rc != 0 and b"multiple of 4" in lib.dvc_last_error()
+    oh, ow = ctypes.c_int32(), ctypes.c_int32()
+    d2 = _lib.DvcConvDesc(1, 4, 27, 45, 8, 3, 2, 1, 1, 1, 1, 1, 0, 0.0, 0, -1, 0, 0, 0)
+    assert lib.dvc_conv2d_out_hw(ctypes.byref(d2), ctypes.byref(oh), ctypes.byref(ow)) == 0
+    assert (oh.value, ow.value) == (14, 23)
+
+
+def test_conv_geometry_matches_torch():
+    import torch.nn.functional as F
+
+    from dvc_amd import ops
+    for (H, W, ks, s, d, p, up, sub) in [(27, 48, 3, 1, 2, 2, 1, 1), (54, 96, 3, 2, 1, 1, 1, 1),
+                                         (13, 24, 3, 1, 1, 1, 2, 1), (27, 45, 3, 1, 1, 1, 1, 2),
+                                         (12, 20, 1, 1, 1, 0, 1, 1)]:
+        x = torch.zeros(1, 1, H, W)
+        if sub == 2:
+            x = x[:, :, ::2, ::2]
+        if up == 2:
+            x = F.interpolate(x, scale_factor=2)
+        y = F.conv2d(x, torch.zeros(1, 1, ks, ks), stride=s, padding=p, dilation=d)
+        assert ops.conv_out_hw(H, W, ks, s, d, p, up, sub) == tuple(y.shape[2:])
+
+
+def test_pack_conv_weight_layout():
+    from dvc_amd import ops
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).view(2, 3, 3, 3)
+    p = ops.pack_conv_weight(w)
+    assert p.shape == (3, 9, 2)
+    for co in range(2):
+        for ci in range(3):
+            for t in range(9):
+                assert p[ci, t, co] == w[co, ci, t // 3, t % 3]
+
+
+def test_state_dict_contract_and_loud_cpu_failure(weights, capsys):
+    from models.ColorVidNet import ColorVidNet
+    from models.NonlocalNet import VGG19_pytorch, WarpNet
+    vgg, warp, col = VGG19_pytorch(), WarpNet(1), ColorVidNet(7)
+    out = capsys.readouterr().out
+    assert "replace all deconv with [nearest + conv]" in out      # ColorVidNet.py:80,85
+    for m, sd in zip((vgg, warp, col), weights):
+        m.load_state_dict(sd, strict=True)
+        assert list(m.state_dict().keys()) == list(sd.keys())
+        assert all(torch.equal(m.state_dict()[k], sd[k]) for k in sd)
+        assert sum(p.numel() for p in m.parameters()) == sum(v.numel() for v in sd.values())
+    assert len(weights[0]) == 32 and len(weights[1]) == 43 and len(weights[2]) == 65
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        vgg(torch.zeros(1, 3, 16, 16), ["r11"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        col(torch.zeros(1, 7, 16, 16))
+    from utils.util import feature_normalize, uncenter_l
+    assert uncenter_l(-50.0) == 0.0
+    with pytest.raises(RuntimeError):
+        feature_normalize(torch.zeros(1, 4, 2, 2))
+
+
+def test_product_code_never_imports_oracle():
+    """The oracle is test infrastructure; nothing under the product package may import it."""
+    pkg = os.path.join(ROOT, "deep-exemplar-based-video-colorization_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                for ln in open(os.path.join(dp, f)).read().splitlines():
+                    assert not re.match(r"\s*(from|import)\s+oracle", ln), (f, ln)
+                    assert "dvc_oracle" not in ln, (f, ln)

@@ -1,0 +1,272 @@
+"""GPU parity, network level: the drop-in modules (models.NonlocalNet / models.ColorVidNet /
+models.FrameColor) vs the CPU oracle and vs the golden vectors recorded from the unmodified reference.
+
+Tolerance policy (SURVEY.md §7 hard part 1, §8c): stages are compared on IDENTICAL stage inputs with
+tight tolerances; end-to-end ab is compared against an fp64 run of the oracle next to the oracle's own
+fp32-vs-fp64 error (the reference's reproducibility floor), and against the reference golden at the
+reference's measured thread-count noise level.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "test_report.txt")
+
+
+def report(line):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(line + "\n")
+
+
+@pytest.fixture(scope="module")
+def nets(weights):
+    import contextlib
+    import io
+    from models.ColorVidNet import ColorVidNet
+    from models.NonlocalNet import VGG19_pytorch, WarpNet
+    sd_v, sd_w, sd_c = weights
+    with contextlib.redirect_stdout(io.StringIO()):
+        vgg, warp, col = VGG19_pytorch(), WarpNet(1), ColorVidNet(7)
+    vgg.load_state_dict(sd_v)
+    warp.load_state_dict(sd_w)
+    col.load_state_dict(sd_c)
+    for m in (vgg, warp, col):
+        m.eval()
+        m.cuda()
+    return vgg, warp, col
+
+
+def rel(got, ref):
+    ref = ref.double()
+    return ((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("H,W", [(48, 80), (216, 384)])
+def test_vgg19_all_keys(nets, weights, H, W):
+    from dvc_amd import arch, synth
+    from oracle import dvc_oracle as O
+    vgg = nets[0]
+    x = O.gray2rgb_batch(synth.synth_lab(5, H, W)[:, 0:1])
+    keys = list(arch.VGG_KEYS)
+    with torch.no_grad():
+        ref = O.vgg19_forward(O.to_dtype(weights[0], torch.float64), x.double(), keys)
+    got = vgg(x.cuda(), keys, preprocess=True)
+    for k, g, r in zip(keys, got, ref):
+        e = rel(g, r)
+        report(f"vgg {H}x{W} {k}: rel_err={e:.2e} shape={tuple(g.shape)}")
+        assert tuple(g.shape) == tuple(r.shape)
+        assert e < 1e-4, (k, e)      # 16 stacked fp32 convs vs fp64 truth
+    # preprocess=False path and avg-pool variant
+    got2 = vgg(x.cuda(), ["r22"], preprocess=False)[0]
+    ref2 = O.vgg19_forward(O.to_dtype(weights[0], torch.float64), x.double(), ["r22"], preprocess=False)[0]
+    assert rel(got2, ref2) < 1e-4
+
+
+def test_vgg_avgpool_variant(weights):
+    from models.NonlocalNet import VGG19_pytorch
+    from oracle import dvc_oracle as O
+    v = VGG19_pytorch(pool="avg")
+    v.load_state_dict(weights[0])
+    v.cuda()
+    x = torch.rand(1, 3, 32, 48)
+    ref = O.vgg19_forward(O.to_dtype(weights[0], torch.float64), x.double(), ["r32"], pool="avg")[0]
+    assert rel(v(x.cuda(), ["r32"])[0], ref) < 1e-4
+
+
+def _norm_feats(sd_v, lab, dtype=torch.float32):
+    from oracle import dvc_oracle as O
+    x = O.gray2rgb_batch(lab[:, 0:1]).to(dtype)
+    f = O.vgg19_forward(O.to_dtype(sd_v, dtype), x, O.VGG_OUT)
+    return [O.feature_normalize(t) for t in f[1:]]
+
+
+@pytest.mark.parametrize("H,W", [(48, 80), (40, 64), (216, 384)])
+def test_warpnet_stages_identical_inputs(nets, weights, H, W):
+    """heads+trunk, theta/phi projection and the fused correlation, each on identical inputs."""
+    from dvc_amd import synth
+    from oracle import dvc_oracle as O
+    warp = nets[1]
+    sd_v, sd_w, _ = weights
+    with torch.no_grad():
+        nA = _norm_feats(sd_v, synth.synth_lab(1000, H, W))
+        nB = _norm_feats(sd_v, synth.synth_lab(2, H, W))
+        sd64 = O.to_dtype(sd_w, torch.float64)
+        fA64 = O.warp_features(sd64, *[t.double() for t in nA])
+    fA = warp.features(*[t.cuda() for t in nA])
+    e = rel(fA, fA64)
+    report(f"warp.features {H}x{W}: rel_err_vs_fp64={e:.2e}")
+    assert e < 2e-4
+    with torch.no_grad():
+        th64 = O.corr_project(sd64, "theta", fA.double().cpu())
+    th = warp.project("theta", fA)
+    e = (th.double().cpu() - th64).abs().max().item()
+    report(f"warp.project {H}x{W}: abs_err={e:.2e}")
+    assert e < 2e-6          # unit-norm columns
+    # full forward vs fp32 oracle (argmax flips possible only on near-ties)
+    IB = synth.synth_lab(2, H, W)
+    for T in (1e-10, 0.01):
+        taps = {}
+        with torch.no_grad():
+            y_ref, sim_ref = O.warpnet_forward(sd_w, IB, *nA, *nB, temperature=T, taps=taps)
+        y, sim, tp = warp(IB.cuda(), *[t.cuda() for t in nA], *[t.cuda() for t in nB], temperature=T,
+                          return_taps=True)
+        gap = taps["top2"][0, :, 0] - taps["top2"][0, :, 1]
+        safe = gap > 1e-4
+        agree = (tp["argmax"][0].cpu().long() == taps["argmax"][0])
+        sim_err = (sim.cpu() - sim_ref).abs().max().item()
+        ys = (tp["y_small"].cpu() - taps["y_small"]).abs().view(3, -1)
+        report(f"warp.forward {H}x{W} T={T}: sim_err={sim_err:.2e} argmax_agree_all={agree.float().mean():.4f} "
+               f"agree_safe={agree[safe].float().mean():.4f} y_err_safe={ys[:, safe].max():.2e} y_err_all={ys.max():.2e}")
+        assert y.shape == y_ref.shape and sim.shape == sim_ref.shape
+        assert sim_err < 1e-4
+        assert agree[safe].float().mean().item() > 0.995
+
+
+def test_warpnet_exemplar_cache_is_bit_identical(nets, weights):
+    from dvc_amd import synth
+    warp = nets[1]
+    with torch.no_grad():
+        nA = [t.cuda() for t in _norm_feats(weights[0], synth.synth_lab(1000, 48, 80))]
+        nB = [t.cuda() for t in _norm_feats(weights[0], synth.synth_lab(2, 48, 80))]
+    IB = synth.synth_lab(2, 48, 80).cuda()
+    y0, s0 = warp(IB, *nA, *nB, temperature=0.01)
+    cache = warp.exemplar_side(IB, *nB)
+    y1, s1 = warp(IB, *nA, *nB, temperature=0.01, exemplar_cache=cache)
+    assert torch.equal(y0, y1) and torch.equal(s0, s1)
+
+
+@pytest.mark.parametrize("H,W", [(48, 80), (216, 384)])
+def test_colorvidnet(nets, weights, H, W):
+    from oracle import dvc_oracle as O
+    col = nets[2]
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 7, H, W, generator=g) * torch.tensor([30, 40, 40, 0.3, 30, 40, 40.]).view(1, 7, 1, 1)
+    with torch.no_grad():
+        ref32 = O.colorvidnet_forward(weights[2], x)
+        ref64 = O.colorvidnet_forward(O.to_dtype(weights[2], torch.float64), x.double())
+    got = col(x.cuda())
+    e_gpu = (got.double().cpu() - ref64).abs()
+    e_cpu = (ref32.double() - ref64).abs()
+    report(f"colorvidnet {H}x{W}: gpu_vs_fp64 max={e_gpu.max():.2e} mean={e_gpu.mean():.2e} | "
+           f"cpu32_vs_fp64 max={e_cpu.max():.2e} mean={e_cpu.mean():.2e}")
+    assert got.shape == ref32.shape
+    # fp32 tolerance on +-128-range output: within 1e-3 or, failing that, no worse than 2x the
+    # reference's own fp32 error on the same input
+    assert e_gpu.max().item() < max(1e-3, 2 * e_cpu.max().item())
+    assert e_gpu.mean().item() < max(1e-4, 2 * e_cpu.mean().item())
+
+
+def _run_clip(nets, H, W, nf, T, cache):
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    vgg, warp, col = nets
+    cc = ClipColorizer(vgg, warp, col, temperature=T, cache_exemplar=cache)
+    cc.set_exemplar(synth.synth_lab(synth.EXEMPLAR_SEED, H, W).cuda())
+    frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W).cuda() for i in range(nf)]
+    outs, warped = [], []
+    last = torch.zeros_like(frames[0])
+    for fr in frames:
+        ab, nl = cc.frame(fr, last)
+        last = torch.cat((fr[:, 0:1], ab), 1)
+        outs.append(ab)
+        warped.append(nl)
+    return outs, warped
+
+
+@pytest.mark.parametrize("name", ["small_48x80_T1e-10", "small_40x64_T0.01", "full_216x384_T1e-10"])
+def test_frame_colorization_vs_reference_golden(nets, golden_dir, name):
+    """End-to-end vs outputs recorded from the UNMODIFIED reference (oracle/pin_reference.py)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    H, W, nf, T = int(g["H"]), int(g["W"]), int(g["n_frames"]), float(g["temperature"])
+    outs, warped = _run_clip(nets, H, W, nf, T, cache=False)
+    gap = g["top2gap0"]
+    for i in range(nf):
+        d = np.abs(outs[i][0].cpu().numpy() - g["ab"][i])
+        wl = np.abs(warped[i][0, :, ::4, ::4].cpu().numpy() - g["warped_lab_small"][i])
+        flips = (wl.max(0) > 1e-3).mean()
+        report(f"e2e golden {name} frame{i}: ab max={d.max():.2e} mean={d.mean():.2e} p99={np.quantile(d, 0.99):.2e} "
+               f"warped rows differing={flips:.5f}")
+        # the reference's own fp32 noise (thread count / fp64) is 2.5e-3..2.8e-3 max-abs on ab
+        # (SURVEY.md §0); near-tie argmax flips move isolated 4x4 blocks.  Bound the bulk tightly.
+        assert np.quantile(d, 0.99) < 2e-3, (name, i)
+        assert d.mean() < 5e-4, (name, i)
+        assert flips < 0.01, (name, i)
+    if T < 1e-6:
+        safe = (gap > 1e-4).reshape(g["sim0"].shape)
+        wl0 = np.abs(warped[0][0, :, ::4, ::4].cpu().numpy() - g["warped_lab_small"][0])
+        assert wl0[:, safe].max() < 1e-3
+
+
+def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights):
+    """The honest form of the 1e-3 claim: GPU-fp32 vs fp64 truth next to CPU-fp32 vs fp64 truth."""
+    from dvc_amd import synth
+    from oracle import dvc_oracle as O
+    H, W, T = 216, 384, 1e-10
+    sd32 = weights
+    sd64 = tuple(O.to_dtype(s, torch.float64) for s in weights)
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
+    fr = synth.synth_lab(synth.FRAME_SEED0, H, W)
+    last = torch.zeros_like(fr)
+    with torch.no_grad():
+        fB32 = O.exemplar_features(IB, sd32[0])
+        ab32, nl32, _ = O.frame_colorization(fr, IB, last, fB32, *sd32, temperature=T)
+        fB64 = O.exemplar_features(IB.double(), sd64[0])
+        ab64, nl64, _ = O.frame_colorization(fr.double(), IB.double(), last.double(), fB64, *sd64, temperature=T)
+    outs, warped = _run_clip(nets, H, W, 1, T, cache=True)
+    e_gpu = (outs[0].double().cpu() - ab64).abs()
+    e_cpu = (ab32.double() - ab64).abs()
+    w_gpu = (warped[0].double().cpu() - nl64).abs()
+    w_cpu = (nl32.double() - nl64).abs()
+    report(f"e2e vs fp64 216x384: GPU ab max={e_gpu.max():.2e} mean={e_gpu.mean():.2e} | CPU32 ab max={e_cpu.max():.2e} "
+           f"mean={e_cpu.mean():.2e} | warped GPU max={w_gpu.max():.2e} CPU32 max={w_cpu.max():.2e}")
+    assert e_gpu.mean().item() < max(1e-3, 3 * e_cpu.mean().item())
+    assert np.quantile(e_gpu.numpy(), 0.999) < max(1e-3, 3 * np.quantile(e_cpu.numpy(), 0.999))
+
+
+def test_clip_recurrence_cached_equals_uncached_and_deterministic(nets):
+    a, _ = _run_clip(nets, 48, 80, 3, 1e-10, cache=True)
+    b, _ = _run_clip(nets, 48, 80, 3, 1e-10, cache=False)
+    c, _ = _run_clip(nets, 48, 80, 3, 1e-10, cache=True)
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
+
+
+def test_drop_in_signature_and_loud_cpu_failure(nets):
+    import inspect
+    from models.FrameColor import frame_colorization, warp_color
+    sig = list(inspect.signature(frame_colorization).parameters)
+    assert sig[:11] == ["IA_lab", "IB_lab", "IA_last_lab", "features_B", "vggnet", "nonlocal_net", "colornet",
+                        "joint_training", "feature_noise", "luminance_noise", "temperature"]
+    assert list(inspect.signature(warp_color).parameters)[:8] == [
+        "IA_l", "IB_lab", "features_B", "vggnet", "nonlocal_net", "colornet", "feature_noise", "temperature"]
+    with pytest.raises(RuntimeError):
+        nets[2](torch.zeros(1, 7, 16, 16))      # CPU tensor must not silently fall back
+
+
+def test_full_res_432x768_properties(nets):
+    """BASELINE configs[3]: N = 20736 positions — size-independent properties only (the oracle would
+    need 7 GB of N x N temporaries): one-hot gather identity, sim in [-1,1], determinism."""
+    from dvc_amd import ops
+    g = torch.Generator().manual_seed(4)
+    h, w = 108, 192
+    P = h * w
+    th = ops.corr_prepare(torch.randn(1, 256, P, generator=g).cuda())
+    ph = ops.corr_prepare(torch.randn(1, 256, P, generator=g).cuda())
+    bl = torch.randn(1, 3, P, generator=g).cuda()
+    o1 = ops.corr_fwd(th, ph, bl, 1e-10, h, w, want_small=True, want_argmax=True)
+    o2 = ops.corr_fwd(th, ph, bl, 1e-10, h, w, want_small=True, want_argmax=True)
+    assert torch.equal(o1["y_small"], o2["y_small"])
+    assert o1["sim_small"].max() <= 1.0 + 1e-5 and o1["sim_small"].min() >= -1.0 - 1e-5
+    gathered = torch.gather(bl, 2, o1["argmax"].long().unsqueeze(1).expand(1, 3, P))
+    same = (o1["y_small"].view(1, 3, P) == gathered).all(1).float().mean().item()
+    assert same > 0.9999
+    # spot-check 64 rows against a direct fp64 evaluation
+    idx = torch.randint(0, P, (64,), generator=g)
+    f = th[0, :, idx.cuda()].double().t() @ ph[0].double()
+    assert (f.max(1)[0].float() - o1["sim_small"].view(-1)[idx.cuda()]).abs().max().item() < 2e-6

@@ -1,0 +1,281 @@
+"""GPU parity, op level: every C-ABI entry point vs. the same ATen CPU op the reference would run
+(evaluated in float64 so the comparison measures OUR rounding only).  Tolerances are stated per test.
+"""
+import os
+import zlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "test_report.txt")
+
+
+def report(line):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(line + "\n")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dvc_amd import ops as o
+    return o
+
+
+def relerr(got, ref):
+    ref = ref.double()
+    return ((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def ref_conv(x, w, b, ksize, stride, dil, pad, pad_mode, in_up, in_sub, scale, shift, slope, res, act, act_slope):
+    v = x.double()
+    N, C = v.shape[:2]
+    if scale is not None:
+        v = v * scale.double().view(N, C, 1, 1) + shift.double().view(N, C, 1, 1)
+    if slope is not None:
+        v = torch.where(v >= 0, v, v * slope.double())
+    if in_sub == 2:
+        v = v[:, :, ::2, ::2]
+    if in_up == 2:
+        v = F.interpolate(v, scale_factor=2, mode="nearest")
+    p = pad
+    if pad_mode == 1 and pad > 0:
+        v = F.pad(v, (pad, pad, pad, pad), mode="reflect")
+        p = 0
+    y = F.conv2d(v, w.double(), None if b is None else b.double(), stride=stride, padding=p, dilation=dil)
+    if res is not None:
+        y = y + res.double()
+    if act == 1:
+        y = F.relu(y)
+    elif act in (2, 3):
+        y = torch.where(y >= 0, y, y * act_slope)
+    elif act == 4:
+        y = torch.tanh(y) * 128
+    return y
+
+
+CONV_CASES = [
+    # name, N, Cin, Cout, H, W, ks, stride, dil, pad, pad_mode, in_up, in_sub, affine, in_prelu, res, act
+    ("vgg_first", 1, 3, 64, 40, 72, 3, 1, 1, 1, 0, 1, 1, True, False, False, 1),
+    ("vgg_mid", 1, 64, 128, 36, 64, 3, 1, 1, 1, 0, 1, 1, False, False, False, 1),
+    ("odd_sizes", 2, 20, 36, 13, 24, 3, 1, 1, 1, 0, 1, 1, False, False, False, 0),
+    ("tw16", 1, 32, 64, 27, 48, 3, 1, 1, 1, 0, 1, 1, False, False, False, 1),
+    ("dil2", 1, 32, 64, 27, 48, 3, 1, 2, 2, 0, 1, 1, True, False, False, 1),
+    ("reflect_s1", 1, 24, 64, 30, 40, 3, 1, 1, 1, 1, 1, 1, False, False, False, 0),
+    ("reflect_s2", 1, 16, 64, 54, 96, 3, 2, 1, 1, 1, 1, 1, True, True, False, 0),
+    ("reflect_up", 2, 16, 64, 13, 24, 3, 1, 1, 1, 1, 2, 1, True, True, False, 0),
+    ("zero_up_res", 1, 32, 32, 27, 48, 3, 1, 1, 1, 0, 2, 1, True, False, True, 1),
+    ("norm_ss", 1, 64, 128, 54, 96, 3, 1, 1, 1, 0, 1, 2, True, False, False, 1),
+    ("norm_ss_odd", 1, 8, 32, 27, 45, 3, 1, 1, 1, 0, 1, 2, True, False, False, 1),
+    ("one_by_one", 2, 256, 256, 12, 20, 1, 1, 1, 0, 0, 1, 1, False, False, False, 0),
+    ("leaky", 1, 16, 32, 20, 33, 3, 1, 1, 1, 0, 1, 1, False, False, False, 3),
+    ("prelu_out", 1, 16, 32, 9, 7, 3, 1, 1, 1, 1, 1, 1, False, False, True, 2),
+    ("cin7", 1, 7, 32, 24, 40, 3, 1, 1, 1, 0, 1, 1, False, False, False, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+def test_conv2d(ops, case, cfg):
+    (name, N, Cin, Cout, H, W, ks, stride, dil, pad, pad_mode, in_up, in_sub, affine, in_prelu, use_res, act) = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    scale = shift = slope = res = None
+    if affine:
+        scale = torch.rand(N * Cin, generator=g) + 0.5
+        shift = torch.randn(N * Cin, generator=g) * 0.3
+    if in_prelu:
+        slope = torch.tensor([0.25])
+    OH, OW = ops.conv_out_hw(H, W, ks, stride, dil, pad, in_up, in_sub)
+    if use_res:
+        res = torch.randn(N, Cout, OH, OW, generator=g)
+    act_slope = 0.2 if act == 3 else 0.3
+    ref = ref_conv(x, w, b, ks, stride, dil, pad, pad_mode, in_up, in_sub, scale, shift, slope, res, act, act_slope)
+    assert tuple(ref.shape) == (N, Cout, OH, OW)
+    d = "cuda"
+    cu = lambda t: None if t is None else t.to(d)
+    act_slope_t = torch.tensor([act_slope], device=d) if act == 2 else None
+    y = ops.conv2d(cu(x), ops.pack_conv_weight(w.to(d)), cu(b), ksize=ks, stride=stride, dil=dil, pad=pad,
+                   pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, act=act, act_slope=act_slope,
+                   act_slope_t=act_slope_t, in_scale=cu(scale), in_shift=cu(shift), in_slope_t=cu(slope),
+                   residual=cu(res), cfg=cfg)
+    torch.cuda.synchronize()
+    e = relerr(y, ref)
+    report(f"conv2d {name} cfg={cfg}: rel_err={e:.3e}")
+    assert e < 2e-5, (name, cfg, e)  # fp32 accumulation over <= 2304 terms
+
+
+def test_conv2d_channel_slice_output(ops):
+    """y may be a channel slice of a wider tensor (WarpNet concat, NonlocalNet.py:464)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 12, 20, generator=g)
+    w = torch.randn(32, 16, 3, 3, generator=g) * 0.1
+    big = torch.full((2, 96, 12, 20), 7.0, device="cuda")
+    ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), None, out=big[:, 32:64], out_batch_stride=96 * 12 * 20)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    assert relerr(big[:, 32:64], ref) < 2e-5
+    assert (big[:, :32] == 7).all() and (big[:, 64:] == 7).all()
+
+
+def test_conv1x1_small(ops):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 128, 17, 23, generator=g)
+    w = torch.randn(2, 128, generator=g) * 0.05
+    b = torch.randn(2, generator=g)
+    y = ops.conv1x1_small(x.cuda(), w.cuda(), b.cuda(), act=ops.ACT_TANH128)
+    ref = torch.tanh(F.conv2d(x.double(), w.double().view(2, 128, 1, 1), b.double())) * 128
+    assert (y.double().cpu() - ref).abs().max().item() < 1e-3   # output range +-128, fp32 tanh
+
+
+def test_instnorm_stats_and_apply(ops):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 24, 26, 48, generator=g) * 3 + 1.5
+    cs = torch.rand(24, generator=g) + 0.5
+    sc, sh = ops.instnorm_stats(x.cuda(), 1e-5)
+    ref = F.instance_norm(x.double(), eps=1e-5)
+    got = x.cuda() * sc.view(2, 24, 1, 1) + sh.view(2, 24, 1, 1)
+    assert (got.double().cpu() - ref).abs().max().item() < 5e-6
+    sc2, sh2 = ops.instnorm_stats(x.cuda(), 1e-5, chan_scale=cs.cuda())
+    got2 = x.cuda() * sc2.view(2, 24, 1, 1) + sh2.view(2, 24, 1, 1)
+    assert (got2.double().cpu() - ref * cs.double().view(1, 24, 1, 1)).abs().max().item() < 1e-5
+    # apply kernel: IN + residual + PReLU
+    res = torch.randn(2, 24, 26, 48, generator=g)
+    slope = torch.tensor([0.2])
+    y = ops.affine_act(x.cuda(), sc, sh, residual=res.cuda(), slope_t=slope.cuda())
+    r = ref + res.double()
+    r = torch.where(r >= 0, r, r * 0.2)
+    assert (y.double().cpu() - r).abs().max().item() < 5e-6
+    # upsample x2 + replicated row pad, written into a channel slice
+    big = torch.zeros(2, 40, 26 * 2 + 2, 96, device="cuda")
+    ops.affine_act(x.cuda(), sc, sh, slope_t=slope.cuda(), up=2, rpad=1, out=big[:, 8:32],
+                   out_batch_stride=40 * 54 * 96)
+    r = F.interpolate(F.prelu(ref, slope.double()), scale_factor=2, mode="nearest")
+    r = F.pad(r, (0, 0, 1, 1), "replicate")
+    assert (big[:, 8:32].double().cpu() - r).abs().max().item() < 5e-6
+    assert (big[:, :8] == 0).all() and (big[:, 32:] == 0).all()
+
+
+def test_pools_upsample_l2norm(ops):
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 5, 27, 49, generator=g)
+    assert torch.equal(ops.maxpool2x2(x.cuda()).cpu(), F.max_pool2d(x, 2, 2))
+    x2 = torch.randn(1, 3, 26, 48, generator=g)
+    assert torch.equal(ops.maxpool2x2(x2.cuda()).cpu(), F.max_pool2d(x2, 2, 2))
+    assert (ops.avgpool2x2(x2.cuda()).cpu() - F.avg_pool2d(x2, 2)).abs().max() < 1e-6
+    x4 = torch.randn(2, 3, 40, 64, generator=g)
+    assert (ops.avgpool4x4(x4.cuda()).cpu() - F.avg_pool2d(x4, 4)).abs().max() < 1e-6
+    assert torch.equal(ops.upsample_nearest(x.cuda(), 4).cpu(), F.interpolate(x, scale_factor=4, mode="nearest"))
+    f = torch.randn(2, 128, 9, 14, generator=g)
+    ref = f.double() / (f.double().norm(2, 1, keepdim=True) + 2.220446049250313e-16)
+    assert (ops.channel_l2norm(f.cuda()).double().cpu() - ref).abs().max().item() < 1e-6
+
+
+def test_colour_glue(ops):
+    from dvc_amd import synth
+    from oracle import dvc_oracle as O
+    lab = synth.synth_lab(11, 32, 48)
+    l = lab[:, 0:1]
+    assert (ops.gray2rgb(lab.cuda()[:, 0:1]).cpu() - O.gray2rgb_batch(l)).abs().max() < 1e-6
+    lab_u = torch.cat((O.uncenter_l(lab[:, 0:1]), lab[:, 1:3]), 1)
+    ref = O.tensor_lab2rgb(lab_u.double())
+    assert (ops.lab2rgb(lab_u.cuda()).double().cpu() - ref).abs().max().item() < 2e-6
+    assert (ops.lab2rgb(lab.cuda(), l_offset=50.0).double().cpu() - ref).abs().max().item() < 2e-6
+    a, w, s, last = (torch.randn(2, 3, 8, 12), torch.randn(2, 3, 8, 12), torch.randn(2, 1, 8, 12),
+                     torch.randn(2, 3, 8, 12))
+    got = ops.pack_color_input(a.cuda(), w.cuda(), s.cuda(), last.cuda()).cpu()
+    assert torch.equal(got, torch.cat((a[:, 0:1], w[:, 1:3], s, last), 1))
+
+
+def _rand_unit(B, C, P, g):
+    t = torch.randn(B, C, P, generator=g)
+    return t
+
+
+@pytest.mark.parametrize("h,w,B", [(10, 16, 1), (9, 9, 2), (12, 20, 1), (54, 96, 1)])
+@pytest.mark.parametrize("T", [1e-10, 0.01])
+def test_corr_fwd_vs_oracle(ops, h, w, B, T):
+    """Fused correlation vs the oracle's materialised N x N path (NonlocalNet.py:477-500)."""
+    from oracle import dvc_oracle as O
+    g = torch.Generator().manual_seed(h * 131 + w)
+    P = h * w
+    raw_t = torch.randn(B, 256, P, generator=g) + 0.3
+    raw_p = torch.randn(B, 256, P, generator=g) - 0.2
+    lab_map = torch.randn(B, 3, 4 * h, 4 * w, generator=g) * 30
+    th = ops.corr_prepare(raw_t.cuda())
+    ph = ops.corr_prepare(raw_p.cuda())
+    # corr_prepare parity (NonlocalNet.py:469-476) in fp64
+    def prep(t):
+        t = t.double()
+        t = t - t.mean(dim=-1, keepdim=True)
+        return t / (t.norm(2, 1, keepdim=True) + O.EPS)
+    assert (th.double().cpu() - prep(raw_t)).abs().max().item() < 1e-6
+    # feed the oracle the SAME fp32 theta/phi the kernel consumes
+    y_ref, sim_ref, f = O.correlate(th.cpu(), ph.cpu(), lab_map, T)
+    blab = ops.avgpool4x4(lab_map.cuda())
+    out = ops.corr_fwd(th, ph, blab.view(B, 3, P), T, h, w, want_small=True, want_argmax=True)
+    torch.cuda.synchronize()
+    sim_err = (out["sim_small"].cpu() - sim_ref).abs().max().item()
+    top2 = torch.topk(f, 2, dim=-1)[0]
+    gap = (top2[..., 0] - top2[..., 1])
+    safe = gap > 2e-6
+    agree = (out["argmax"].cpu().long() == f.argmax(-1))
+    y_err_all = (out["y_small"].cpu() - y_ref).abs().view(B, 3, P)
+    y_err_safe = y_err_all.permute(0, 2, 1)[safe].max().item() if safe.any() else 0.0
+    report(f"corr_fwd h={h} w={w} B={B} T={T}: sim_err={sim_err:.2e} argmax_agree={agree.float().mean():.5f} "
+           f"safe_rows={safe.float().mean():.4f} y_err_safe={y_err_safe:.2e} y_err_all={y_err_all.max():.2e}")
+    assert sim_err < 2e-6
+    assert agree[safe].all()
+    # tolerance: y in Lab units (|values| ~ 100); one-hot regime is exact gather, soft regime fp32 softmax
+    assert y_err_safe < (1e-4 if T < 1e-6 else 2e-3)
+    # upsampled outputs are exact nearest x4 copies of the small ones
+    assert torch.equal(out["y_up"], F.interpolate(out["y_small"], scale_factor=4, mode="nearest"))
+    assert torch.equal(out["sim_up"], F.interpolate(out["sim_small"], scale_factor=4, mode="nearest"))
+    if T < 1e-6:
+        # size-independent property: the output IS the pooled exemplar colour at the argmax
+        gathered = torch.gather(blab.view(B, 3, P), 2, out["argmax"].long().unsqueeze(1).expand(B, 3, P))
+        rows = safe.unsqueeze(1).expand(B, 3, P).cuda()
+        assert torch.equal(out["y_small"].view(B, 3, P)[rows], gathered[rows])
+
+
+def test_corr_fwd_wta(ops):
+    from oracle import dvc_oracle as O
+    g = torch.Generator().manual_seed(77)
+    h, w, B = 12, 20, 1
+    P = h * w
+    th = ops.corr_prepare(torch.randn(B, 256, P, generator=g).cuda())
+    ph = ops.corr_prepare(torch.randn(B, 256, P, generator=g).cuda())
+    lab_map = torch.randn(B, 3, 4 * h, 4 * w, generator=g) * 30
+    y_ref, sim_ref, _ = O.correlate(th.cpu(), ph.cpu(), lab_map, 0.01, WTA_scale_weight=0.5)
+    blab = ops.avgpool4x4(lab_map.cuda())
+    out = ops.corr_fwd(th, ph, blab.view(B, 3, P), 0.01, h, w, wta_scale=0.5, want_small=True)
+    assert (out["sim_small"].cpu() - sim_ref).abs().max().item() < 2e-6
+    # WTA compares f == rowmax exactly; the oracle's GEMM rounds differently, so only rows whose
+    # maximum is unique at 1e-6 are comparable
+    assert (out["y_small"].cpu() - y_ref).abs().max().item() < 5e-3
+
+
+def test_corr_deterministic(ops):
+    g = torch.Generator().manual_seed(3)
+    h, w = 27, 48
+    P = h * w
+    th = ops.corr_prepare(torch.randn(1, 256, P, generator=g).cuda())
+    ph = ops.corr_prepare(torch.randn(1, 256, P, generator=g).cuda())
+    bl = torch.randn(1, 3, P, generator=g).cuda()
+    a = ops.corr_fwd(th, ph, bl, 0.01, h, w, want_small=True)
+    b = ops.corr_fwd(th, ph, bl, 0.01, h, w, want_small=True)
+    assert torch.equal(a["y_small"], b["y_small"]) and torch.equal(a["sim_small"], b["sim_small"])
+
+
+def test_errors_are_loud(ops):
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 4, 8, 8), torch.zeros(4, 9, 4), None)          # CPU tensor
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 4, 8, 8).cuda(), torch.zeros(4, 9, 6).cuda(), None)  # Cout % 4 != 0
+    with pytest.raises(ValueError):
+        ops.corr_fwd(torch.zeros(1, 256, 16).cuda(), torch.zeros(1, 256, 16).cuda(), torch.zeros(1, 3, 16).cuda(),
+                     0.0, 4, 4)

@@ -1,0 +1,29 @@
+#!/bin/bash
+# One GPU-box round trip: GPU parity tests, smoke, a short bench and a rocprofv3 kernel trace.
+# Everything is logged under gpurun_out/ (merged back by gpurun).  Usage:
+#   gpurun --timeout 1800 -- 'bash tools/gpu_check.sh [tests|bench|prof|all]'
+what=${1:-all}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+rm -f gpurun_out/test_report.txt
+(rocminfo | grep -E "Marketing Name|gfx9" | sort | uniq -c; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket") > gpurun_out/box.txt 2>&1
+if [[ $what == all || $what == tests ]]; then
+  timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider ${PYTEST_ARGS} > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+  tail -n 40 gpurun_out/pytest_gpu.log
+  timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
+  tail -n 4 gpurun_out/smoke.log
+fi
+if [[ $what == all || $what == bench ]]; then
+  timeout 900 python bench.py --steps 30 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err
+  echo "bench rc=$?"; cat gpurun_out/bench.json; tail -n 5 gpurun_out/bench.err
+fi
+if [[ $what == all || $what == prof ]]; then
+  rm -rf gpurun_out/prof
+  timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o trace -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err
+  echo "prof rc=$?"; cat gpurun_out/prof_bench.json
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
+  [[ -n "$f" ]] && head -n 40 "$f"
+  # keep only the summaries (the raw trace is large)
+  find gpurun_out/prof -name "*kernel_trace.csv" -size +8M -delete
+fi
