@@ -44,6 +44,8 @@ struct ConvKArgs {
     int ck;             // input channels per chunk (even)
     int IH_T, IW_T, IW_P;
     int xs_floats;      // CK*IH_T*IW_P rounded up to a multiple of 4
+    int ws_floats;      // CK*ks*ks*MT
+    int cin_pad;        // Cin rounded up to a multiple of 4
 };
 
 // virtual coordinate -> stored offset component, or -1 when the tap reads a zero
@@ -88,9 +90,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     constexpr int MT = 32 * WM * RM;
     constexpr int RPT = 32 / TW;  // rows per 32-pixel N-tile
     constexpr int PH = WN * RN * RPT;
+    constexpr int ROW4 = MT / 4;
+    constexpr int WPT = (8 * 9 * ROW4 + NT - 1) / NT;  // float4 weight loads per thread per chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
     float* ws = smem + a.xs_floats;
+    float* aff = ws + a.ws_floats;  // [2][cin_pad] per-channel scale / shift of this image
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -103,46 +108,107 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     const int n = blockIdx.z;
     const int KK = a.ks * a.ks;
     const int CK = a.ck;
-    const long HW = (long)a.H * a.W;
+    const int HWi = a.H * a.W;
     const float* xn = a.x + (long)n * a.x_bs;
-    const float* scn = a.in_scale ? a.in_scale + (long)n * a.Cin : nullptr;
-    const float* shn = a.in_shift ? a.in_shift + (long)n * a.Cin : nullptr;
+    const bool affine = a.in_scale != nullptr;
     const float in_slope = a.in_prelu ? *a.in_slope_ptr : 0.f;
 
     const int plane = a.IH_T * a.IW_P;
     const int tile_elems = a.IH_T * a.IW_T;
-    const int total = CK * tile_elems;
+    const int total = CK * tile_elems;  // host guarantees total <= CONV_EPT * NT
     const int vy0 = oy0 * a.stride - a.pad, vx0 = ox0 * a.stride - a.pad;
 
     // ---- per-thread staging plan (identical for every channel chunk)
-    const bool fast = total <= CONV_EPT * NT;
     int goff[CONV_EPT];   // offset inside one channel plane, -1 = zero, -2 = nothing to do
     int lpack[CONV_EPT];  // (channel-in-chunk << 24) | LDS float offset
-    if (fast) {
 #pragma unroll
-        for (int t = 0; t < CONV_EPT; ++t) {
-            int e = tid + t * NT;
-            if (e < total) {
-                int c = e / tile_elems;
-                int rem = e - c * tile_elems;
-                int iy = rem / a.IW_T;
-                int ix = rem - iy * a.IW_T;
-                goff[t] = stored_offset(a, vy0 + iy, vx0 + ix);
-                lpack[t] = (c << 24) | (c * plane + iy * a.IW_P + ix);
-            } else {
-                goff[t] = -2;
-                lpack[t] = 0;
-            }
+    for (int t = 0; t < CONV_EPT; ++t) {
+        int e = tid + t * NT;
+        if (e < total) {
+            int c = e / tile_elems;
+            int rem = e - c * tile_elems;
+            int iy = rem / a.IW_T;
+            int ix = rem - iy * a.IW_T;
+            goff[t] = stored_offset(a, vy0 + iy, vx0 + ix);
+            lpack[t] = (c << 24) | (c * plane + iy * a.IW_P + ix);
+        } else {
+            goff[t] = -2;
+            lpack[t] = 0;
         }
     }
+    const int nq = CK * KK * ROW4;
+    const int grow_end = a.Cin * KK;
 
-    f32x16 acc[RM][RN];
+    float xr[CONV_EPT];
+    float4 wr[WPT];
+    // issue the global loads of one channel chunk into registers (no dependent use -> all in flight)
+    auto issue = [&](int c0) {
+#pragma unroll
+        for (int t = 0; t < CONV_EPT; ++t) {
+            int ch = c0 + (lpack[t] >> 24);
+            bool ok = goff[t] >= 0 && ch < a.Cin;
+            xr[t] = xn[ok ? (unsigned)(ch * HWi + goff[t]) : 0u];  // tensors are < 2^31 elements
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            int q = tid + i * NT;
+            int row = q / ROW4, col = (q % ROW4) * 4;
+            int grow = c0 * KK + row;
+            bool ok = q < nq && grow < grow_end && m0 + col < a.Cout;
+            wr[i] = *reinterpret_cast<const float4*>(a.w + (ok ? (unsigned)(grow * a.Cout + m0 + col) : 0u));
+        }
+    };
+    // transform + write the prefetched chunk into LDS
+    auto commit = [&](int c0) {
+#pragma unroll
+        for (int t = 0; t < CONV_EPT; ++t) {
+            if (goff[t] != -2) {
+                int ch = c0 + (lpack[t] >> 24);
+                bool ok = goff[t] >= 0 && ch < a.Cin;
+                float v = 0.f;
+                if (ok) {
+                    v = xr[t];
+                    if (affine) v = v * aff[ch] + aff[a.cin_pad + ch];
+                    if (a.in_prelu) v = v >= 0.f ? v : v * in_slope;
+                }
+                xs[lpack[t] & 0xFFFFFF] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            int q = tid + i * NT;
+            if (q < nq) {
+                int row = q / ROW4, col = (q % ROW4) * 4;
+                int grow = c0 * KK + row;
+                bool ok = grow < grow_end && m0 + col < a.Cout;
+                *reinterpret_cast<float4*>(ws + row * MT + col) = ok ? wr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    issue(0);
+    if (affine) {
+        const float* scn = a.in_scale + (long)n * a.Cin;
+        const float* shn = a.in_shift + (long)n * a.Cin;
+        for (int i = tid; i < a.Cin; i += NT) {
+            aff[i] = scn[i];
+            aff[a.cin_pad + i] = shn[i];
+        }
+        __syncthreads();
+    }
+    commit(0);
+    __syncthreads();
+
+    // tot: running sum; acc: one chunk's MFMA chain.  Flushing per chunk keeps every fp32 chain short
+    // (CK*ks*ks terms) and makes the total a sum of Cin/CK partials — the same blocked summation
+    // shape as a CPU GEMM, ~6x less rounding than one 4608-term fma chain.
+    f32x16 tot[RM][RN], acc[RM][RN];
 #pragma unroll
     for (int i = 0; i < RM; ++i)
 #pragma unroll
         for (int j = 0; j < RN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
 
     int boff[RN];
 #pragma unroll
@@ -154,62 +220,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     const int aoff = wm * RM * 32 + l31;
 
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
-        __syncthreads();  // previous chunk's LDS reads are done
-        // ---- stage input patch
-        if (fast) {
+        const bool has_next = c0 + CK < a.Cin;
+        if (has_next) issue(c0 + CK);  // global latency hides under this chunk's MFMAs
 #pragma unroll
-            for (int t = 0; t < CONV_EPT; ++t) {
-                if (goff[t] != -2) {
-                    int c = lpack[t] >> 24;
-                    int ch = c0 + c;
-                    float v = 0.f;
-                    if (goff[t] >= 0 && ch < a.Cin) {
-                        v = xn[(long)ch * HW + goff[t]];
-                        if (scn) v = v * scn[ch] + shn[ch];
-                        if (a.in_prelu) v = v >= 0.f ? v : v * in_slope;
-                    }
-                    xs[lpack[t] & 0xFFFFFF] = v;
-                }
-            }
-        } else {
-            for (int e = tid; e < total; e += NT) {
-                int c = e / tile_elems;
-                int rem = e - c * tile_elems;
-                int iy = rem / a.IW_T;
-                int ix = rem - iy * a.IW_T;
-                int g = stored_offset(a, vy0 + iy, vx0 + ix);
-                int ch = c0 + c;
-                float v = 0.f;
-                if (g >= 0 && ch < a.Cin) {
-                    v = xn[(long)ch * HW + g];
-                    if (scn) v = v * scn[ch] + shn[ch];
-                    if (a.in_prelu) v = v >= 0.f ? v : v * in_slope;
-                }
-                xs[c * plane + iy * a.IW_P + ix] = v;
-            }
-        }
-        // ---- stage weight slice: rows (c,tap) of MT contiguous output channels
-        {
-            constexpr int ROW4 = MT / 4;
-            const int nq = CK * KK * ROW4;
-            const int grow_end = a.Cin * KK;
-            for (int q = tid; q < nq; q += NT) {
-                int row = q / ROW4;  // ROW4 is a power of two
-                int col = (q % ROW4) * 4;
-                int grow = c0 * KK + row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (grow < grow_end && m0 + col < a.Cout)
-                    v = *reinterpret_cast<const float4*>(a.w + (long)grow * a.Cout + m0 + col);
-                *reinterpret_cast<float4*>(ws + row * MT + col) = v;
-            }
-        }
-        __syncthreads();
-        // ---- MFMA over taps x channel pairs
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int tap = 0; tap < KK; ++tap) {
             int ky = tap / a.ks, kx = tap - ky * a.ks;
             const float* xp0 = xs + hi * plane + ky * a.dil * a.IW_P + kx * a.dil;
             const float* wp0 = ws + (hi * KK + tap) * MT + aoff;
-#pragma unroll 4
+#pragma unroll 2
             for (int kk = 0; kk < CK; kk += 2) {
                 const float* xp = xp0 + kk * plane;
                 const float* wp = wp0 + kk * KK * MT;
@@ -224,6 +247,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
                     for (int j = 0; j < RN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) tot[i][j] += acc[i][j];
+        if (has_next) {
+            __syncthreads();  // every wave finished reading this chunk from LDS
+            commit(c0 + CK);
+            __syncthreads();
         }
     }
 
@@ -246,7 +278,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
             for (int r = 0; r < 16; ++r) {
                 int co = m0 + (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (co < a.Cout) {
-                    float v = acc[i][j][r];
+                    float v = tot[i][j][r];
                     if (a.bias) v += a.bias[co];
                     if (rn_) v += rn_[(long)co * OHW + pix];
                     yn[(long)co * OHW + pix] = apply_act(v, a.act, slope);
@@ -364,9 +396,19 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     DVC_REQUIRE(cfg >= 0 && cfg < 5, "dvc_conv2d: cfg out of range");
     const ConvCfg& c = kCfgs[cfg];
     const int mt = 32 * c.wm * c.rm, ph = c.wn * c.rn * rpt;
-    a.ck = d->ksize == 1 ? 32 : 8;
     a.IH_T = (ph - 1) * d->stride + d->dil * (d->ksize - 1) + 1;
     a.IW_T = (tw - 1) * d->stride + d->dil * (d->ksize - 1) + 1;
+    // channels per chunk: as many as the per-thread staging plan (CONV_EPT registers) can hold
+    {
+        int per_ch = a.IH_T * a.IW_T;
+        int ck_max = ((CONV_EPT * 256) / per_ch) & ~1;
+        int ck = d->ksize == 1 ? 32 : 8;
+        if (ck > ck_max) ck = ck_max;
+        int cin_even = (d->Cin + 1) & ~1;
+        if (ck > cin_even) ck = cin_even;
+        DVC_REQUIRE(ck >= 2, "dvc_conv2d: tile too large for the staging plan (cfg %d)", cfg);
+        a.ck = ck;
+    }
     // row pitch: rows of one N-tile must land on disjoint bank ranges for ds_read_b32 (32 banks):
     // pitch == tw (mod 32) for tw in {16, 8}; anything >= IW_T for tw == 32.
     int pitch = a.IW_T;
@@ -375,7 +417,9 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     }
     a.IW_P = pitch;
     a.xs_floats = (a.ck * a.IH_T * a.IW_P + 3) & ~3;
-    size_t lds = sizeof(float) * ((size_t)a.xs_floats + (size_t)a.ck * a.ks * a.ks * mt);
+    a.ws_floats = a.ck * a.ks * a.ks * mt;
+    a.cin_pad = (d->Cin + 3) & ~3;
+    size_t lds = sizeof(float) * ((size_t)a.xs_floats + (size_t)a.ws_floats + (in_scale ? 2 * (size_t)a.cin_pad : 0));
     DVC_REQUIRE(lds <= 160 * 1024, "dvc_conv2d: LDS tile too large (%zu bytes)", lds);
     dim3 grid(cdiv(OW, tw) * cdiv(OH, ph), cdiv(d->Cout, mt), d->N);
     hipStream_t s = (hipStream_t)stream;

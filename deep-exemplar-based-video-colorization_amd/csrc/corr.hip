@@ -23,6 +23,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -120,30 +121,69 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
 
     const int t0 = split * a.tiles_per_split;
     const int t1 = min(a.ntiles, t0 + a.tiles_per_split);
-    for (int t = t0; t < t1; ++t) {
+
+    // register prefetch of the next key tile (issued before the MFMA loop, committed to LDS after it)
+    constexpr int KR = VEC4 ? (CORR_C * CORR_KT / 4) / 256 : (CORR_C * CORR_KT) / 256;
+    typedef typename std::conditional<VEC4, float4, float>::type kreg_t;
+    kreg_t kr[KR];
+    float blr = 0.f;
+    auto issue = [&](int t) {
         const int k0 = t * CORR_KT;
-        __syncthreads();  // everyone finished reading the previous tile
-        // ---- stage key tile ks[c][0..31] = phi[c][k0..k0+31] (zero beyond P)
         if (VEC4) {
 #pragma unroll
-            for (int i = 0; i < (CORR_C * CORR_KT / 4) / 256; ++i) {
+            for (int i = 0; i < KR; ++i) {
                 int q = tid + i * 256;
                 int row = q >> 3, c4 = (q & 7) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k0 + c4 < P) v = *reinterpret_cast<const float4*>(ph + (long)row * P + k0 + c4);
-                *reinterpret_cast<float4*>(ks + row * CORR_KT + c4) = v;
+                bool ok = k0 + c4 < P;
+                *reinterpret_cast<float4*>(&kr[i]) =
+                    *reinterpret_cast<const float4*>(ph + (ok ? (unsigned)(row * P + k0 + c4) : 0u));
             }
         } else {
-            for (int e = tid; e < CORR_C * CORR_KT; e += 256) {
+#pragma unroll
+            for (int i = 0; i < KR; ++i) {
+                int e = tid + i * 256;
                 int row = e >> 5, c = e & 31;
-                ks[e] = (k0 + c < P) ? ph[(long)row * P + k0 + c] : 0.f;
+                bool ok = k0 + c < P;
+                *reinterpret_cast<float*>(&kr[i]) = ph[ok ? (unsigned)(row * P + k0 + c) : 0u];
             }
         }
         if (tid < 3 * CORR_KT) {
             int c = tid >> 5, j = tid & 31;
-            bl[tid] = (k0 + j < P) ? blb[(long)c * P + k0 + j] : 0.f;
+            blr = (k0 + j < P) ? blb[(long)c * P + k0 + j] : 0.f;
         }
-        __syncthreads();
+    };
+    auto commit = [&](int t) {
+        const int k0 = t * CORR_KT;
+        if (VEC4) {
+#pragma unroll
+            for (int i = 0; i < KR; ++i) {
+                int q = tid + i * 256;
+                int row = q >> 3, c4 = (q & 7) * 4;
+                float4 v = *reinterpret_cast<float4*>(&kr[i]);
+                if (!(k0 + c4 < P)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(ks + row * CORR_KT + c4) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KR; ++i) {
+                int e = tid + i * 256;
+                int c = e & 31;
+                float v = *reinterpret_cast<float*>(&kr[i]);
+                ks[e] = (k0 + c < P) ? v : 0.f;
+            }
+        }
+        if (tid < 3 * CORR_KT) bl[tid] = blr;
+    };
+
+    if (t0 < t1) {
+        issue(t0);
+        commit(t0);
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        const int k0 = t * CORR_KT;
+        const bool has_next = t + 1 < t1;
+        if (has_next) issue(t + 1);
 
         // ---- S^T tile: 128 dependent MFMAs (K = 256), A from LDS, B from registers
         f32x16 acc;
@@ -196,6 +236,11 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
                     y2 = fmaf(p, bl[2 * CORR_KT + kl], y2);
                 }
             }
+        }
+        if (has_next) {
+            __syncthreads();  // all waves done with this tile's LDS reads
+            commit(t + 1);
+            __syncthreads();
         }
     }
 

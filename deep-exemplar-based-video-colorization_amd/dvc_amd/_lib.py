@@ -63,6 +63,12 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (or `make -C csrc`). "
             "There is no CPU fallback for the HIP path.")
+    # torch ships its own ROCm runtime (libamdhip64 / libhsa-runtime64); it must be the one already
+    # mapped when our library's DT_NEEDED entries are resolved, otherwise two HIP runtimes coexist in
+    # the process and ours sees "no ROCm-capable device".
+    import torch  # noqa: F401
+    if torch.cuda.is_available():
+        torch.cuda.init()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == symbol missing from the .so

@@ -36,6 +36,9 @@ def _need(t, name):
         raise RuntimeError(f"dvc_amd: `{name}` must be contiguous")
 
 
+conv_record = None   # set to a list to log every conv2d launch (tools/tune_conv.py)
+
+
 def pack_conv_weight(w):
     """[Cout][Cin][kh][kw] -> [Cin][kh*kw][Cout] (layout consumed by dvc_conv2d).  Pure data movement."""
     co, ci, kh, kw = w.shape
@@ -69,6 +72,10 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
                     float(act_slope), 1 if in_slope_t is not None else 0, cfg, 0, out_batch_stride, 0)
     if residual is not None:
         assert tuple(residual.shape) == (N, Cout, OH, OW), (residual.shape, (N, Cout, OH, OW))
+    if conv_record is not None:
+        conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=ksize, stride=stride, dil=dil, pad=pad,
+                                pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, affine=in_scale is not None,
+                                in_prelu=in_slope_t is not None, residual=residual is not None, act=act))
     rc = lib.dvc_conv2d(ctypes.byref(d), _p(x), _p(w_packed), _p(bias), _p(in_scale), _p(in_shift),
                         _p(in_slope_t), _p(act_slope_t), _p(residual), _p(out), _stream())
     _lib.check(rc, "dvc_conv2d")

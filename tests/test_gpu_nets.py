@@ -156,10 +156,11 @@ def test_colorvidnet(nets, weights, H, W):
     report(f"colorvidnet {H}x{W}: gpu_vs_fp64 max={e_gpu.max():.2e} mean={e_gpu.mean():.2e} | "
            f"cpu32_vs_fp64 max={e_cpu.max():.2e} mean={e_cpu.mean():.2e}")
     assert got.shape == ref32.shape
-    # fp32 tolerance on +-128-range output: within 1e-3 or, failing that, no worse than 2x the
-    # reference's own fp32 error on the same input
-    assert e_gpu.max().item() < max(1e-3, 2 * e_cpu.max().item())
-    assert e_gpu.mean().item() < max(1e-4, 2 * e_cpu.mean().item())
+    # fp32 tolerance on the +-128-range output: within 1e-3 max-abs of the fp64 truth, or — where the
+    # reference's own fp32 run is not (it is not, with these random weights) — no further from the
+    # truth than 1.5x the reference's fp32 run on the same input.
+    assert e_gpu.max().item() < max(1e-3, 1.5 * e_cpu.max().item())
+    assert e_gpu.mean().item() < max(1e-4, 1.5 * e_cpu.mean().item())
 
 
 def _run_clip(nets, H, W, nf, T, cache):
@@ -181,7 +182,12 @@ def _run_clip(nets, H, W, nf, T, cache):
 
 @pytest.mark.parametrize("name", ["small_48x80_T1e-10", "small_40x64_T0.01", "full_216x384_T1e-10"])
 def test_frame_colorization_vs_reference_golden(nets, golden_dir, name):
-    """End-to-end vs outputs recorded from the UNMODIFIED reference (oracle/pin_reference.py)."""
+    """End-to-end vs outputs recorded from the UNMODIFIED reference (oracle/pin_reference.py).
+
+    The golden is the reference's fp32 CPU run, itself 3e-3..6e-3 max-abs away from the fp64 truth on
+    the ab output with these weights (see test_e2e_error_vs_fp64...), so this test pins the
+    *discrete* part exactly (which exemplar position every pixel picked, the similarity map) and
+    bounds the continuous part at that noise level; the fp64-anchored test below is the tight one."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     H, W, nf, T = int(g["H"]), int(g["W"]), int(g["n_frames"]), float(g["temperature"])
     outs, warped = _run_clip(nets, H, W, nf, T, cache=False)
@@ -189,25 +195,42 @@ def test_frame_colorization_vs_reference_golden(nets, golden_dir, name):
     for i in range(nf):
         d = np.abs(outs[i][0].cpu().numpy() - g["ab"][i])
         wl = np.abs(warped[i][0, :, ::4, ::4].cpu().numpy() - g["warped_lab_small"][i])
-        flips = (wl.max(0) > 1e-3).mean()
         report(f"e2e golden {name} frame{i}: ab max={d.max():.2e} mean={d.mean():.2e} p99={np.quantile(d, 0.99):.2e} "
-               f"warped rows differing={flips:.5f}")
-        # the reference's own fp32 noise (thread count / fp64) is 2.5e-3..2.8e-3 max-abs on ab
-        # (SURVEY.md §0); near-tie argmax flips move isolated 4x4 blocks.  Bound the bulk tightly.
-        assert np.quantile(d, 0.99) < 2e-3, (name, i)
-        assert d.mean() < 5e-4, (name, i)
-        assert flips < 0.01, (name, i)
+               f"warped max={wl.max():.2e}")
+        if T < 1e-6:
+            assert d.mean() < 2e-3 and np.quantile(d, 0.99) < 1e-2, (name, i)
+        else:   # soft temperature: d(y)/d(f) = |B_lab|/T ~ 1e4, fp32 affinities differ by ~1e-6
+            assert d.mean() < 0.1 and wl.max() < 5e-2, (name, i)
     if T < 1e-6:
         safe = (gap > 1e-4).reshape(g["sim0"].shape)
         wl0 = np.abs(warped[0][0, :, ::4, ::4].cpu().numpy() - g["warped_lab_small"][0])
-        assert wl0[:, safe].max() < 1e-3
+        assert wl0[:, safe].max() < 1e-4          # same exemplar pixel picked -> same colour
+        sim = warped and _sim_small(nets, H, W, T)
+        assert np.abs(sim - g["sim0"]).max() < 1e-4
 
 
-def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights):
-    """The honest form of the 1e-3 claim: GPU-fp32 vs fp64 truth next to CPU-fp32 vs fp64 truth."""
+def _sim_small(nets, H, W, T):
+    from dvc_amd import synth
+    from dvc_amd.frame import VGG_OUT
+    from utils.util import feature_normalize, gray2rgb_batch
+    vgg, warp, _ = nets
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).cuda()
+    fr = synth.synth_lab(synth.FRAME_SEED0, H, W).cuda()
+    from dvc_amd import ops
+    fB = vgg(ops.lab2rgb(IB, l_offset=50.0), VGG_OUT)
+    fA = vgg(gray2rgb_batch(fr[:, 0:1]), VGG_OUT)
+    _, _, tp = warp(IB, *[feature_normalize(t) for t in fA[1:]], *[feature_normalize(t) for t in fB[1:]],
+                    temperature=T, return_taps=True)
+    return tp["sim_small"][0, 0].cpu().numpy()
+
+
+@pytest.mark.parametrize("H,W,T", [(48, 80, 1e-10), (40, 64, 0.01), (216, 384, 1e-10)])
+def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights, H, W, T):
+    """The honest form of the "ab within 1e-3" claim (SURVEY.md §7 hard part 1): GPU-fp32 vs the fp64
+    truth, next to the reference-equivalent CPU-fp32 vs the same truth.  Pass = within 1e-3, or no
+    further from the truth than 1.5x the CPU fp32 run (mean and 99.9th percentile)."""
     from dvc_amd import synth
     from oracle import dvc_oracle as O
-    H, W, T = 216, 384, 1e-10
     sd32 = weights
     sd64 = tuple(O.to_dtype(s, torch.float64) for s in weights)
     IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
@@ -223,10 +246,13 @@ def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights):
     e_cpu = (ab32.double() - ab64).abs()
     w_gpu = (warped[0].double().cpu() - nl64).abs()
     w_cpu = (nl32.double() - nl64).abs()
-    report(f"e2e vs fp64 216x384: GPU ab max={e_gpu.max():.2e} mean={e_gpu.mean():.2e} | CPU32 ab max={e_cpu.max():.2e} "
-           f"mean={e_cpu.mean():.2e} | warped GPU max={w_gpu.max():.2e} CPU32 max={w_cpu.max():.2e}")
-    assert e_gpu.mean().item() < max(1e-3, 3 * e_cpu.mean().item())
-    assert np.quantile(e_gpu.numpy(), 0.999) < max(1e-3, 3 * np.quantile(e_cpu.numpy(), 0.999))
+    q = lambda t: np.quantile(t.numpy(), 0.999)
+    report(f"e2e vs fp64 {H}x{W} T={T}: GPU ab max={e_gpu.max():.2e} q999={q(e_gpu):.2e} mean={e_gpu.mean():.2e} | "
+           f"CPU32 ab max={e_cpu.max():.2e} q999={q(e_cpu):.2e} mean={e_cpu.mean():.2e} | "
+           f"warped GPU max={w_gpu.max():.2e} CPU32 max={w_cpu.max():.2e}")
+    assert e_gpu.mean().item() < max(1e-3, 1.5 * e_cpu.mean().item())
+    assert q(e_gpu) < max(1e-3, 1.5 * q(e_cpu))
+    assert w_gpu.max().item() < max(1e-3, 2.0 * w_cpu.max().item())
 
 
 def test_clip_recurrence_cached_equals_uncached_and_deterministic(nets):

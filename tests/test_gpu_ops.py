@@ -183,8 +183,11 @@ def test_colour_glue(ops):
     assert (ops.gray2rgb(lab.cuda()[:, 0:1]).cpu() - O.gray2rgb_batch(l)).abs().max() < 1e-6
     lab_u = torch.cat((O.uncenter_l(lab[:, 0:1]), lab[:, 1:3]), 1)
     ref = O.tensor_lab2rgb(lab_u.double())
-    assert (ops.lab2rgb(lab_u.cuda()).double().cpu() - ref).abs().max().item() < 2e-6
-    assert (ops.lab2rgb(lab.cuda(), l_offset=50.0).double().cpu() - ref).abs().max().item() < 2e-6
+    # fp32 cube / matrix / gamma chain vs fp64 truth: the CPU fp32 oracle itself is ~3e-6 off
+    e_cpu = (O.tensor_lab2rgb(lab_u).double() - ref).abs().max().item()
+    tol = max(1e-5, 2 * e_cpu)
+    assert (ops.lab2rgb(lab_u.cuda()).double().cpu() - ref).abs().max().item() < tol
+    assert (ops.lab2rgb(lab.cuda(), l_offset=50.0).double().cpu() - ref).abs().max().item() < tol
     a, w, s, last = (torch.randn(2, 3, 8, 12), torch.randn(2, 3, 8, 12), torch.randn(2, 1, 8, 12),
                      torch.randn(2, 3, 8, 12))
     got = ops.pack_color_input(a.cuda(), w.cuda(), s.cuda(), last.cuda()).cpu()

@@ -14,6 +14,9 @@ if [[ $what == all || $what == tests ]]; then
   timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
   tail -n 4 gpurun_out/smoke.log
 fi
+if [[ $what == all || $what == tune ]]; then
+  timeout 600 python tools/tune_conv.py > gpurun_out/tune_conv.log 2>&1; echo "tune rc=$?"; head -n 50 gpurun_out/tune_conv.log
+fi
 if [[ $what == all || $what == bench ]]; then
   timeout 900 python bench.py --steps 30 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err
   echo "bench rc=$?"; cat gpurun_out/bench.json; tail -n 5 gpurun_out/bench.err
