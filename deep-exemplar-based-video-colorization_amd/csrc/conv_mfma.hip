@@ -84,14 +84,16 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     }
 }
 
-template <int WM, int WN, int RM, int RN, int TW>
+template <int WM, int WN, int RM, int RN, int TW, int KS>
 __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     constexpr int NT = 64 * WM * WN;
+    constexpr int KK = KS * KS;
+    constexpr int CK = KS == 3 ? 8 : 16;  // input channels per chunk (compile-time: the MFMA loop fully unrolls)
     constexpr int MT = 32 * WM * RM;
     constexpr int RPT = 32 / TW;  // rows per 32-pixel N-tile
     constexpr int PH = WN * RN * RPT;
     constexpr int ROW4 = MT / 4;
-    constexpr int WPT = (8 * 9 * ROW4 + NT - 1) / NT;  // float4 weight loads per thread per chunk
+    constexpr int WPT = (CK * KK * ROW4 + NT - 1) / NT;  // float4 weight loads per thread per chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
     float* ws = smem + a.xs_floats;
@@ -106,8 +108,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     const int ox0 = bx * TW, oy0 = by * PH;
     const int m0 = blockIdx.y * MT;
     const int n = blockIdx.z;
-    const int KK = a.ks * a.ks;
-    const int CK = a.ck;
     const int HWi = a.H * a.W;
     const float* xn = a.x + (long)n * a.x_bs;
     const bool affine = a.in_scale != nullptr;
@@ -210,14 +210,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
 
-    int boff[RN];
+    int xbase[RN];  // per-lane LDS offset of this lane's pixel (tap 0, channel `hi`)
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
         int t = wn * RN + j;
         int r = l31 / TW, c = l31 % TW;
-        boff[j] = ((t * RPT + r) * a.stride) * a.IW_P + c * a.stride;
+        xbase[j] = hi * plane + ((t * RPT + r) * a.stride) * a.IW_P + c * a.stride;
     }
-    const int aoff = wm * RM * 32 + l31;
+    const float* wbase = ws + hi * KK * MT + wm * RM * 32 + l31;
+    const int dIW = a.dil * a.IW_P;
 
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         const bool has_next = c0 + CK < a.Cin;
@@ -228,19 +229,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
             for (int j = 0; j < RN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // fully unrolled: KK*CK/2 k-steps; weight offsets are immediates, the compiler hoists the
+        // ds_reads of later steps above the MFMAs of earlier ones (no LDS latency between MFMAs)
+#pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
-            int ky = tap / a.ks, kx = tap - ky * a.ks;
-            const float* xp0 = xs + hi * plane + ky * a.dil * a.IW_P + kx * a.dil;
-            const float* wp0 = ws + (hi * KK + tap) * MT + aoff;
-#pragma unroll 2
+            const int ky = tap / KS, kx = tap % KS;
+            const int toff = ky * dIW + kx * a.dil;
+#pragma unroll
             for (int kk = 0; kk < CK; kk += 2) {
-                const float* xp = xp0 + kk * plane;
-                const float* wp = wp0 + kk * KK * MT;
                 float av[RM], bv[RN];
 #pragma unroll
-                for (int i = 0; i < RM; ++i) av[i] = wp[i * 32];
+                for (int i = 0; i < RM; ++i) av[i] = wbase[(kk * KK + tap) * MT + i * 32];
 #pragma unroll
-                for (int j = 0; j < RN; ++j) bv[j] = xp[boff[j]];
+                for (int j = 0; j < RN; ++j) bv[j] = xs[xbase[j] + kk * plane + toff];
 #pragma unroll
                 for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -301,13 +302,24 @@ static const ConvCfg kCfgs[5] = {
     {2, 2, 1, 1},  // 4: 64 co x 2 N-tiles
 };
 
-template <int WM, int WN, int RM, int RN>
+template <int WM, int WN, int RM, int RN, int KS>
 static void launch_tw(int tw, dim3 grid, size_t lds, hipStream_t s, const ConvKArgs& a) {
     constexpr int NT = 64 * WM * WN;
     switch (tw) {
-        case 32: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 32>), grid, dim3(NT), lds, s, a); break;
-        case 16: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 16>), grid, dim3(NT), lds, s, a); break;
-        default: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 8>), grid, dim3(NT), lds, s, a); break;
+        case 32: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 32, KS>), grid, dim3(NT), lds, s, a); break;
+        case 16: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 16, KS>), grid, dim3(NT), lds, s, a); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 8, KS>), grid, dim3(NT), lds, s, a); break;
+    }
+}
+
+template <int KS>
+static void launch_cfg(int cfg, int tw, dim3 grid, size_t lds, hipStream_t s, const ConvKArgs& a) {
+    switch (cfg) {
+        case 0: launch_tw<1, 4, 2, 2, KS>(tw, grid, lds, s, a); break;
+        case 1: launch_tw<1, 4, 1, 2, KS>(tw, grid, lds, s, a); break;
+        case 2: launch_tw<1, 4, 2, 1, KS>(tw, grid, lds, s, a); break;
+        case 3: launch_tw<1, 4, 1, 1, KS>(tw, grid, lds, s, a); break;
+        default: launch_tw<2, 2, 1, 1, KS>(tw, grid, lds, s, a); break;
     }
 }
 
@@ -377,12 +389,22 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
 
     const int tw = pick_tw(OW);
     const int rpt = 32 / tw;
+    const int ck = d->ksize == 3 ? 8 : 16;
+    // a configuration is usable when one chunk of its input patch fits the per-thread staging plan
+    auto fits = [&](int i) {
+        const ConvCfg& c = kCfgs[i];
+        int ph = c.wn * c.rn * rpt;
+        int ih = (ph - 1) * d->stride + d->dil * (d->ksize - 1) + 1;
+        int iw = (tw - 1) * d->stride + d->dil * (d->ksize - 1) + 1;
+        return ck * ih * iw <= CONV_EPT * 256;
+    };
     int cfg = d->cfg;
     if (cfg < 0) {
         // largest tile that still gives >= 2 waves per SIMD (2048 waves); else >= 1; else most waves
-        int first1 = -1, first2 = -1, most = 0;
+        int first1 = -1, first2 = -1, most = -1;
         long most_waves = -1;
         for (int i = 0; i < 5; ++i) {
+            if (!fits(i)) continue;
             const ConvCfg& c = kCfgs[i];
             int mt = 32 * c.wm * c.rm, ph = c.wn * c.rn * rpt;
             long waves = 4L * cdiv(OW, tw) * cdiv(OH, ph) * cdiv(d->Cout, mt) * d->N;
@@ -392,23 +414,15 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
             if (waves > most_waves) { most_waves = waves; most = i; }
         }
         cfg = first2 >= 0 ? first2 : (first1 >= 0 ? first1 : most);
+        DVC_REQUIRE(cfg >= 0, "dvc_conv2d: no tile configuration fits this geometry");
     }
     DVC_REQUIRE(cfg >= 0 && cfg < 5, "dvc_conv2d: cfg out of range");
+    DVC_REQUIRE(fits(cfg), "dvc_conv2d: tile configuration %d does not fit this geometry", cfg);
     const ConvCfg& c = kCfgs[cfg];
     const int mt = 32 * c.wm * c.rm, ph = c.wn * c.rn * rpt;
+    a.ck = ck;
     a.IH_T = (ph - 1) * d->stride + d->dil * (d->ksize - 1) + 1;
     a.IW_T = (tw - 1) * d->stride + d->dil * (d->ksize - 1) + 1;
-    // channels per chunk: as many as the per-thread staging plan (CONV_EPT registers) can hold
-    {
-        int per_ch = a.IH_T * a.IW_T;
-        int ck_max = ((CONV_EPT * 256) / per_ch) & ~1;
-        int ck = d->ksize == 1 ? 32 : 8;
-        if (ck > ck_max) ck = ck_max;
-        int cin_even = (d->Cin + 1) & ~1;
-        if (ck > cin_even) ck = cin_even;
-        DVC_REQUIRE(ck >= 2, "dvc_conv2d: tile too large for the staging plan (cfg %d)", cfg);
-        a.ck = ck;
-    }
     // row pitch: rows of one N-tile must land on disjoint bank ranges for ds_read_b32 (32 banks):
     // pitch == tw (mod 32) for tw in {16, 8}; anything >= IW_T for tw == 32.
     int pitch = a.IW_T;
@@ -423,13 +437,8 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     DVC_REQUIRE(lds <= 160 * 1024, "dvc_conv2d: LDS tile too large (%zu bytes)", lds);
     dim3 grid(cdiv(OW, tw) * cdiv(OH, ph), cdiv(d->Cout, mt), d->N);
     hipStream_t s = (hipStream_t)stream;
-    switch (cfg) {
-        case 0: launch_tw<1, 4, 2, 2>(tw, grid, lds, s, a); break;
-        case 1: launch_tw<1, 4, 1, 2>(tw, grid, lds, s, a); break;
-        case 2: launch_tw<1, 4, 2, 1>(tw, grid, lds, s, a); break;
-        case 3: launch_tw<1, 4, 1, 1>(tw, grid, lds, s, a); break;
-        default: launch_tw<2, 2, 1, 1>(tw, grid, lds, s, a); break;
-    }
+    if (d->ksize == 3) launch_cfg<3>(cfg, tw, grid, lds, s, a);
+    else launch_cfg<1>(cfg, tw, grid, lds, s, a);
     DVC_CHECK_LAUNCH("dvc_conv2d");
     return 0;
 }

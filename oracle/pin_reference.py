@@ -46,6 +46,8 @@ def import_reference():
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
+        import models.NonlocalNet as _nl
+        assert _nl.__file__.startswith(REF), _nl.__file__
         from models.NonlocalNet import VGG19_pytorch, WarpNet
         from models.ColorVidNet import ColorVidNet
         from models.FrameColor import frame_colorization
@@ -68,12 +70,17 @@ CASES = [
 
 
 def main(write=True):
+    # import the reference FIRST, while our own drop-in `models` / `utils` are not importable
+    for p in (PKG,):
+        while p in sys.path:
+            sys.path.remove(p)
+    VGG19_pytorch, WarpNet, ColorVidNet, ref_frame_colorization, rutil = import_reference()
+    assert VGG19_pytorch.__module__ == "models.NonlocalNet" and "/root/reference" in sys.modules[
+        VGG19_pytorch.__module__].__file__ if VGG19_pytorch.__module__ in sys.modules else True
     sys.path.insert(0, PKG)
     sys.path.insert(0, ROOT)
     from dvc_amd import synth
     from oracle import dvc_oracle as O
-
-    VGG19_pytorch, WarpNet, ColorVidNet, ref_frame_colorization, rutil = import_reference()
     torch.manual_seed(0)
     import contextlib
     import io
@@ -130,16 +137,15 @@ def main(write=True):
         print(f"{name}: oracle == reference bit-exact on ab / warped_lab / features_A "
               f"(lab2rgb max diff {d_rgb:.1e})")
         if write:
-            tp = taps[0]
             np.savez_compressed(
                 os.path.join(GOLD, name + ".npz"),
                 H=H, W=W, n_frames=nf, temperature=T,
                 exemplar_rgb_sum=np.float64(rgb_ref.double().sum().item()),
                 ab=np.stack([o[0][0].numpy() for o in ref_out]),
                 warped_lab_small=np.stack([o[1][0, :, ::4, ::4].numpy() for o in ref_out]),
-                argmax0=tp["argmax"][0].numpy().astype(np.int32),
-                sim0=tp["sim_small"][0, 0].numpy(),
-                top2gap0=(tp["top2"][0, :, 0] - tp["top2"][0, :, 1]).numpy(),
+                argmax=np.stack([tp["argmax"][0].numpy().astype(np.int32) for tp in taps]),
+                sim=np.stack([tp["sim_small"][0, 0].numpy() for tp in taps]),
+                top2gap=np.stack([(tp["top2"][0, :, 0] - tp["top2"][0, :, 1]).numpy() for tp in taps]),
                 r52_mean=np.array([o[2][4].double().mean().item() for o in ref_out]),
                 r12_absmean=np.array([o[2][0].double().abs().mean().item() for o in ref_out]),
             )

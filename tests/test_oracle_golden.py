@@ -40,16 +40,15 @@ def test_oracle_matches_reference_golden(golden_dir, weights, name):
             last = torch.cat((fr[:, 0:1], ab), dim=1)
             d_ab = np.abs(ab[0].numpy() - g["ab"][i]).max()
             assert d_ab <= 5e-3, (name, i, d_ab)
-            if i == 0:
-                gap = g["top2gap0"]
-                safe = gap > 1e-5
-                am = taps["argmax"][0].numpy()
-                assert (am[safe] == g["argmax0"][safe]).all()
-                assert np.abs(taps["sim_small"][0, 0].numpy() - g["sim0"]).max() <= 1e-5
-                if T < 1e-6:
-                    d_nl = np.abs(nl[0, :, ::4, ::4].numpy() - g["warped_lab_small"][i])
-                    rows = safe.reshape(d_nl.shape[1:])
-                    assert d_nl[:, rows].max() <= 1e-4
+            gap = g["top2gap"][i]
+            safe = gap > 1e-5
+            am = taps["argmax"][0].numpy()
+            assert (am[safe] == g["argmax"][i][safe]).all()
+            assert np.abs(taps["sim_small"][0, 0].numpy() - g["sim"][i]).max() <= 1e-5
+            if T < 1e-6:
+                d_nl = np.abs(nl[0, :, ::4, ::4].numpy() - g["warped_lab_small"][i])
+                rows = safe.reshape(d_nl.shape[1:])
+                assert d_nl[:, rows].max() <= 1e-4
             assert abs(fA[4].double().mean().item() - g["r52_mean"][i]) <= 1e-4 * max(1.0, abs(g["r52_mean"][i]))
 
 

@@ -30,3 +30,12 @@ if [[ $what == all || $what == prof ]]; then
   # keep only the summaries (the raw trace is large)
   find gpurun_out/prof -name "*kernel_trace.csv" -size +8M -delete
 fi
+if [[ $what == pmc || $what == all2 ]]; then
+  rm -rf gpurun_out/pmc*; 
+  rocprofv3 -L > gpurun_out/counters_list.txt 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pmc1 -o p -- python tools/prof_kernels.py > gpurun_out/pmc1.log 2>&1; echo "pmc1 rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc2 -o p -- python tools/prof_kernels.py > gpurun_out/pmc2.log 2>&1; echo "pmc2 rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc3 -o p -- python tools/prof_kernels.py > gpurun_out/pmc3.log 2>&1; echo "pmc3 rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU --output-format csv -d gpurun_out/pmc4 -o p -- python tools/prof_kernels.py > gpurun_out/pmc4.log 2>&1; echo "pmc4 rc=$?"
+  ls gpurun_out/pmc*/ ; tail -3 gpurun_out/pmc1.log gpurun_out/pmc4.log
+fi

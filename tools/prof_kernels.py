@@ -1,0 +1,30 @@
+"""Short kernel-only workload for rocprofv3 --pmc passes: the fused correlation at P=5184 and a few
+representative conv layers (each launched a handful of times)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deep-exemplar-based-video-colorization_amd"))
+import torch  # noqa: E402
+
+from dvc_amd import ops  # noqa: E402
+
+dev = torch.device("cuda")
+g = torch.Generator().manual_seed(1)
+h, w = 54, 96
+P = h * w
+th = ops.corr_prepare(torch.randn(1, 256, P, generator=g).to(dev))
+ph = ops.corr_prepare(torch.randn(1, 256, P, generator=g).to(dev))
+bl = torch.randn(1, 3, P, generator=g).to(dev)
+for _ in range(5):
+    ops.corr_fwd(th, ph, bl, 1e-10, h, w)
+shapes = [(512, 512, 27, 48, 1), (256, 256, 54, 96, 1), (128, 128, 216, 384, 1), (128, 128, 108, 192, 1),
+          (512, 512, 27, 48, 2), (64, 64, 216, 384, 1)]
+for (ci, co, H, W, dil) in shapes:
+    x = torch.randn(1, ci, H, W, device=dev)
+    wt = torch.randn(ci, 9, co, device=dev) * 0.05
+    b = torch.randn(co, device=dev)
+    for _ in range(3):
+        ops.conv2d(x, wt, b, dil=dil, pad=dil, act=1)
+torch.cuda.synchronize()
+print("done")
