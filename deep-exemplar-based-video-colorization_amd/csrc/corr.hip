@@ -94,10 +94,14 @@ struct CorrArgs {
     int P, ntiles, tiles_per_split, nslot;
 };
 
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
 template <bool WTA, bool VEC4>
 __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
-    __shared__ __attribute__((aligned(16))) float ks[CORR_C * CORR_KT + 3 * CORR_KT];
-    float* bl = ks + CORR_C * CORR_KT;
+    // two key tiles (double buffer, 2 x 32 KB) + two pooled-Lab tiles [2][256] (first 96 floats used)
+    __shared__ __attribute__((aligned(16))) float smem[2 * CORR_C * CORR_KT + 2 * 256];
+    float* bl = smem + 2 * CORR_C * CORR_KT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -122,127 +126,138 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     const int t0 = split * a.tiles_per_split;
     const int t1 = min(a.ntiles, t0 + a.tiles_per_split);
 
-    // register prefetch of the next key tile (issued before the MFMA loop, committed to LDS after it)
-    constexpr int KR = VEC4 ? (CORR_C * CORR_KT / 4) / 256 : (CORR_C * CORR_KT) / 256;
-    typedef typename std::conditional<VEC4, float4, float>::type kreg_t;
-    kreg_t kr[KR];
+    // ---- key-tile staging into smem[buf][c][0..31] = phi[c][k0..k0+31]
+    // VEC4 (P % 4 == 0): LDS-DMA, no VGPRs — a wave instruction moves 8 rows x 128 B (lane -> row
+    // lane/8, 16-byte column lane%8); keys beyond P read a valid in-row address (their affinities are
+    // masked to -inf later).  Otherwise: scalar loads staged through registers.
+    // Everything in the steady-state loop is branch-free (one basic block) so that the scheduler can
+    // interleave the matrix and vector streams.
     float blr = 0.f;
-    auto issue = [&](int t) {
+    float kr[VEC4 ? 1 : (CORR_C * CORR_KT) / 256];
+    const int blc = tid < 3 * CORR_KT ? (tid >> 5) : 0, blj = tid & 31;
+    auto issue = [&](int t, int buf) {
         const int k0 = t * CORR_KT;
         if (VEC4) {
+            float* kb = smem + buf * CORR_C * CORR_KT;
 #pragma unroll
-            for (int i = 0; i < KR; ++i) {
-                int q = tid + i * 256;
-                int row = q >> 3, c4 = (q & 7) * 4;
-                bool ok = k0 + c4 < P;
-                *reinterpret_cast<float4*>(&kr[i]) =
-                    *reinterpret_cast<const float4*>(ph + (ok ? (unsigned)(row * P + k0 + c4) : 0u));
+            for (int i = 0; i < 8; ++i) {
+                const int c = i * 4 + wave;  // 1 KB chunk = rows 8c .. 8c+7
+                const int row = c * 8 + (lane >> 3), col = (lane & 7) * 4;
+                const float* src = ph + (unsigned)(row * P + (k0 + col < P ? k0 + col : 0));
+                __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(kb + c * 256), 16, 0, 0);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < KR; ++i) {
+            for (int i = 0; i < (CORR_C * CORR_KT) / 256; ++i) {
                 int e = tid + i * 256;
                 int row = e >> 5, c = e & 31;
-                bool ok = k0 + c < P;
-                *reinterpret_cast<float*>(&kr[i]) = ph[ok ? (unsigned)(row * P + k0 + c) : 0u];
+                kr[VEC4 ? 0 : i] = ph[(k0 + c < P) ? (unsigned)(row * P + k0 + c) : 0u];
             }
         }
-        if (tid < 3 * CORR_KT) {
-            int c = tid >> 5, j = tid & 31;
-            blr = (k0 + j < P) ? blb[(long)c * P + k0 + j] : 0.f;
-        }
+        blr = blb[(k0 + blj < P) ? (unsigned)(blc * P + k0 + blj) : 0u];  // lanes >= 96 fill unused slots
     };
-    auto commit = [&](int t) {
-        const int k0 = t * CORR_KT;
-        if (VEC4) {
+    auto commit = [&](int buf) {
+        if (!VEC4) {
+            float* kb = smem + buf * CORR_C * CORR_KT;
 #pragma unroll
-            for (int i = 0; i < KR; ++i) {
-                int q = tid + i * 256;
-                int row = q >> 3, c4 = (q & 7) * 4;
-                float4 v = *reinterpret_cast<float4*>(&kr[i]);
-                if (!(k0 + c4 < P)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(ks + row * CORR_KT + c4) = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < KR; ++i) {
-                int e = tid + i * 256;
-                int c = e & 31;
-                float v = *reinterpret_cast<float*>(&kr[i]);
-                ks[e] = (k0 + c < P) ? v : 0.f;
-            }
+            for (int i = 0; i < (CORR_C * CORR_KT) / 256; ++i) kb[tid + i * 256] = kr[VEC4 ? 0 : i];
         }
-        if (tid < 3 * CORR_KT) bl[tid] = blr;
+        bl[buf * 256 + tid] = blr;
     };
 
-    if (t0 < t1) {
-        issue(t0);
-        commit(t0);
-    }
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-        const int k0 = t * CORR_KT;
-        const bool has_next = t + 1 < t1;
-        if (has_next) issue(t + 1);
-
-        // ---- S^T tile: 128 dependent MFMAs (K = 256), A from LDS, B from registers
-        f32x16 acc;
+    // ---- online softmax, split so that it runs in the shadow of the next tile's MFMA chain.
+    // All special cases are IEEE arithmetic (no branches): masked keys carry -inf (expf(-inf) = 0),
+    // m_use replaces an all-masked running max of -inf by 0 so (-inf) - (-inf) is never formed.
+    float pv[16];            // pending tile's affinities after WTA / masking
+    float tmax_pend = -INFINITY;
+    float m_use = 0.f;
+    const float* blp = bl;   // pooled-Lab tile of the pending tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* kp = ks + hi * CORR_KT + l31;
-#pragma unroll
-        for (int s = 0; s < CORR_C / 2; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s * CORR_KT], qreg[s], acc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) pv[r] = -INFINITY;
 
-        // ---- lane-local online softmax over this lane's 16 keys of its query
+    // (1) right after a tile's MFMA chain: row max / argmax bookkeeping, WTA, masking
+    auto finish_tile = [&](const f32x16& sacc, int k0) {
         float tilemax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float f = acc[r];
+            float f = sacc[r];
             const bool kvalid = key < P;
-            if (kvalid && f > fmax) {  // strict '>' keeps the lowest index on ties
-                fmax = f;
-                amax = key;
-            }
+            const bool better = kvalid & (f > fmax);  // strict '>' keeps the lowest index on ties
+            fmax = better ? f : fmax;
+            amax = better ? key : amax;
             if (WTA) f = (f == fq) ? f : f * a.wta_scale;
             f = kvalid ? f : -INFINITY;
-            acc[r] = f;
+            pv[r] = f;
             tilemax = fmaxf(tilemax, f);
         }
-        if (tilemax > -INFINITY) {
-            const float tmax = tilemax / a.T;
-            if (tmax > m) {
-                const float sc = expf(m - tmax);  // m == -inf on first use -> 0
-                l *= sc;
-                y0 *= sc;
-                y1 *= sc;
-                y2 *= sc;
-                m = tmax;
-            }
-            // candidates: exp(f/T - m) can only be non-zero in fp32 within ~104 of the max; the slack
-            // also covers the rounding of f*invT vs the exact division (ulp(m) can be ~1e3 at T=1e-10)
-            const float slack = 120.f + fabsf(m) * 4.8e-7f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float f = acc[r];
-                if (f * a.invT - m > -slack) {
-                    const float tt = f / a.T;
-                    const float p = expf(tt - m);
-                    const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    l += p;
-                    y0 = fmaf(p, bl[kl], y0);
-                    y1 = fmaf(p, bl[CORR_KT + kl], y1);
-                    y2 = fmaf(p, bl[2 * CORR_KT + kl], y2);
-                }
-            }
-        }
-        if (has_next) {
-            __syncthreads();  // all waves done with this tile's LDS reads
-            commit(t + 1);
-            __syncthreads();
-        }
+        tmax_pend = tilemax;
+    };
+    // (2) new running max + rescale of the running sums (true division, as ATen's f / T)
+    auto rescale = [&]() {
+        const float m_new = fmaxf(m, tmax_pend / a.T);
+        m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float sc = expf(m - m_use);  // m == -inf -> 0 (the sums are still 0 then)
+        l *= sc;
+        y0 *= sc;
+        y1 *= sc;
+        y2 *= sc;
+        m = m_new;
+    };
+    // (3) one pending affinity: p = exp(f/T - m), accumulate the sum and the colour numerator
+    auto element = [&](int r) {
+        const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float pe = expf(pv[r] / a.T - m_use);
+        l += pe;
+        y0 = fmaf(pe, blp[kl], y0);
+        y1 = fmaf(pe, blp[CORR_KT + kl], y1);
+        y2 = fmaf(pe, blp[2 * CORR_KT + kl], y2);
+    };
+
+    if (t0 < t1) {
+        issue(t0, 0);
+        commit(0);
     }
+    __syncthreads();  // (drains the LDS-DMA of the first tile)
+    for (int t = t0; t < t1; ++t) {
+        const int cur = (t - t0) & 1;
+        issue(min(t + 1, t1 - 1), cur ^ 1);  // (the last iteration re-stages its own tile: harmless)
+
+        // S^T tile of THIS key tile: 128 dependent MFMAs (K = 256) in 16 segments of 8.  The softmax of
+        // the PREVIOUS tile is spliced in, one affinity per segment.  An in-order wave overlaps VALU with
+        // an MFMA only if the VALU sits between that MFMA and the next (dependent) one, so each segment
+        // is pinned with sched_barrier and interleaved 1 MFMA : 1 LDS read : ~10 VALU inside.
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* kp = smem + cur * CORR_C * CORR_KT + hi * CORR_KT + l31;
+        asm volatile("" : "+v"(acc), "+v"(l), "+v"(y0), "+v"(y1), "+v"(y2));
+#pragma unroll
+        for (int seg = 0; seg < 16; ++seg) {
+#pragma unroll
+            for (int s = seg * 8; s < seg * 8 + 8; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s * CORR_KT], qreg[s], acc, 0, 0, 0);
+            if (seg == 0) rescale();
+            element(seg);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // VALU
+            }
+            // data fence: ties the matrix stream (acc) and the vector stream (l, y*) to this point so
+            // that neither can be hoisted / sunk out of its segment by earlier passes
+            asm volatile("" : "+v"(acc), "+v"(l), "+v"(y0), "+v"(y1), "+v"(y2));
+        }
+        finish_tile(acc, t * CORR_KT);
+        blp = bl + cur * 256;
+        commit(cur ^ 1);
+        __syncthreads();  // next tile landed (DMA drained / stores visible); this tile's reads done
+    }
+    // drain: softmax of the last tile
+    rescale();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) element(r);
 
     // ---- write this lane's partial state: slot = split*2 + hi
     if (qvalid) {
@@ -257,39 +272,67 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     }
 }
 
-// merge the 2*nsplit partial states of each query; write small + x4-upsampled outputs
+// merge the 2*nsplit partial states of each query; write small + x4-upsampled outputs.
+// Workgroup = 64 queries x 4 slot groups: the slot loop is 4x shorter and 4x more loads are in flight
+// than with one thread per query (this kernel is pure L2 latency).
 __global__ __launch_bounds__(256) void corr_merge_kernel(const float* __restrict__ part, int nslot, int P,
                                                          int h, int w, float* __restrict__ y_small,
                                                          float* __restrict__ sim_small,
                                                          float* __restrict__ y_up,
                                                          float* __restrict__ sim_up,
                                                          int* __restrict__ argmax) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float sh[4][7][64];
+    const int qx_ = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + qx_;
     const int b = blockIdx.y;
-    if (q >= P) return;
-    const float* pb = part + (long)b * nslot * CORR_NF * P + q;
+    const bool ok = q < P;
+    const float* pb = part + (long)b * nslot * CORR_NF * P + (ok ? q : 0);
+    // pass 1 (this group's slots): running max of m, best (fmax, argmax)
     float M = -INFINITY, F = -INFINITY;
     int A = 0x7fffffff;
-    for (int s = 0; s < nslot; ++s) {
+    for (int s = g; s < nslot; s += 4) {
         const float* ps = pb + (long)s * CORR_NF * P;
         M = fmaxf(M, ps[0]);
         float f = ps[5L * P];
         int ai = __float_as_int(ps[6L * P]);
-        if (f > F || (f == F && ai < A)) {
-            F = f;
-            A = ai;
-        }
+        bool better = f > F || (f == F && ai < A);
+        F = better ? f : F;
+        A = better ? ai : A;
     }
+    sh[g][0][qx_] = M;
+    sh[g][5][qx_] = F;
+    sh[g][6][qx_] = __int_as_float(A);
+    __syncthreads();
+    M = fmaxf(fmaxf(sh[0][0][qx_], sh[1][0][qx_]), fmaxf(sh[2][0][qx_], sh[3][0][qx_]));
+    // pass 2: rescaled sums of this group's slots
     float L = 0.f, Y0 = 0.f, Y1 = 0.f, Y2 = 0.f;
-    for (int s = 0; s < nslot; ++s) {
+    for (int s = g; s < nslot; s += 4) {
         const float* ps = pb + (long)s * CORR_NF * P;
         float ms = ps[0];
-        if (ms == -INFINITY) continue;
-        float sc = expf(ms - M);
+        float sc = (ms == -INFINITY) ? 0.f : expf(ms - M);
         L = fmaf(ps[(long)P], sc, L);
         Y0 = fmaf(ps[2L * P], sc, Y0);
         Y1 = fmaf(ps[3L * P], sc, Y1);
         Y2 = fmaf(ps[4L * P], sc, Y2);
+    }
+    sh[g][1][qx_] = L;
+    sh[g][2][qx_] = Y0;
+    sh[g][3][qx_] = Y1;
+    sh[g][4][qx_] = Y2;
+    __syncthreads();
+    if (g != 0 || !ok) return;
+    L = (sh[0][1][qx_] + sh[1][1][qx_]) + (sh[2][1][qx_] + sh[3][1][qx_]);
+    Y0 = (sh[0][2][qx_] + sh[1][2][qx_]) + (sh[2][2][qx_] + sh[3][2][qx_]);
+    Y1 = (sh[0][3][qx_] + sh[1][3][qx_]) + (sh[2][3][qx_] + sh[3][3][qx_]);
+    Y2 = (sh[0][4][qx_] + sh[1][4][qx_]) + (sh[2][4][qx_] + sh[3][4][qx_]);
+    F = sh[0][5][qx_];
+    A = __float_as_int(sh[0][6][qx_]);
+    for (int k = 1; k < 4; ++k) {
+        float f = sh[k][5][qx_];
+        int ai = __float_as_int(sh[k][6][qx_]);
+        bool better = f > F || (f == F && ai < A);
+        F = better ? f : F;
+        A = better ? ai : A;
     }
     const float yv[3] = {Y0 / L, Y1 / L, Y2 / L};
     if (y_small)
@@ -359,7 +402,7 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(cdiv(P, CORR_QB), nsplit, B);
     const bool vec4 = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(phi) & 15) == 0);
-    dim3 mgrid(cdiv(P, 256), B);
+    dim3 mgrid(cdiv(P, 64), B);
     const bool wta = wta_scale != 1.0f;
     if (wta) {
         // pass 1: row maxima only (identical MFMA order => `f == rowmax` is exact in pass 2)
