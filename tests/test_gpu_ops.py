@@ -100,10 +100,17 @@ def test_conv2d(ops, case, cfg):
     d = "cuda"
     cu = lambda t: None if t is None else t.to(d)
     act_slope_t = torch.tensor([act_slope], device=d) if act == 2 else None
-    y = ops.conv2d(cu(x), ops.pack_conv_weight(w.to(d)), cu(b), ksize=ks, stride=stride, dil=dil, pad=pad,
-                   pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, act=act, act_slope=act_slope,
-                   act_slope_t=act_slope_t, in_scale=cu(scale), in_shift=cu(shift), in_slope_t=cu(slope),
-                   residual=cu(res), cfg=cfg)
+    try:
+        y = ops.conv2d(cu(x), ops.pack_conv_weight(w.to(d)), cu(b), ksize=ks, stride=stride, dil=dil, pad=pad,
+                       pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, act=act, act_slope=act_slope,
+                       act_slope_t=act_slope_t, in_scale=cu(scale), in_shift=cu(shift), in_slope_t=cu(slope),
+                       residual=cu(res), cfg=cfg)
+    except RuntimeError as e:
+        # an explicitly requested tile configuration may not fit the stride-2 staging plan; the
+        # automatic choice (cfg = -1) must always work
+        if cfg >= 0 and "does not fit" in str(e):
+            pytest.skip(str(e))
+        raise
     torch.cuda.synchronize()
     e = relerr(y, ref)
     report(f"conv2d {name} cfg={cfg}: rel_err={e:.3e}")
