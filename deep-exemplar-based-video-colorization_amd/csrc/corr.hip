@@ -99,8 +99,10 @@ struct CorrArgs {
 
 template <bool WTA, bool VEC4>
 __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
-    // two key tiles (double buffer, 2 x 32 KB) + two pooled-Lab tiles [2][256] (first 96 floats used)
-    __shared__ __attribute__((aligned(16))) float smem[2 * CORR_C * CORR_KT + 2 * 256];
+    // two key tiles (double buffer, 2 x 32 KB) + three pooled-Lab tiles [3][256] (first 96 floats used).
+    // Three, because with ONE barrier per iteration the pending tile's Lab (read during the chain by slow
+    // waves) and the next tile's Lab (written after the chain by fast waves) must never share a buffer.
+    __shared__ __attribute__((aligned(16))) float smem[2 * CORR_C * CORR_KT + 3 * 256];
     float* bl = smem + 2 * CORR_C * CORR_KT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -156,13 +158,13 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         }
         blr = blb[(k0 + blj < P) ? (unsigned)(blc * P + k0 + blj) : 0u];  // lanes >= 96 fill unused slots
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, int lbuf) {
         if (!VEC4) {
             float* kb = smem + buf * CORR_C * CORR_KT;
 #pragma unroll
             for (int i = 0; i < (CORR_C * CORR_KT) / 256; ++i) kb[tid + i * 256] = kr[VEC4 ? 0 : i];
         }
-        bl[buf * 256 + tid] = blr;
+        bl[lbuf * 256 + tid] = blr;
     };
 
     // ---- online softmax, split so that it runs in the shadow of the next tile's MFMA chain.
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
 
     if (t0 < t1) {
         issue(t0, 0);
-        commit(0);
+        commit(0, 0);
     }
     __syncthreads();  // (drains the LDS-DMA of the first tile)
     for (int t = t0; t < t1; ++t) {
@@ -250,8 +252,8 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
             asm volatile("" : "+v"(acc), "+v"(l), "+v"(y0), "+v"(y1), "+v"(y2));
         }
         finish_tile(acc, t * CORR_KT);
-        blp = bl + cur * 256;
-        commit(cur ^ 1);
+        blp = bl + ((t - t0) % 3) * 256;
+        commit(cur ^ 1, (t + 1 - t0) % 3);
         __syncthreads();  // next tile landed (DMA drained / stores visible); this tile's reads done
     }
     // drain: softmax of the last tile

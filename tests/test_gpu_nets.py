@@ -128,6 +128,54 @@ def test_warpnet_stages_identical_inputs(nets, weights, H, W):
         assert agree[safe].float().mean().item() > 0.995
 
 
+@pytest.mark.parametrize("seed", [1000, 1001, 1002, 1003])
+def test_correlation_on_real_features_self_consistent(nets, weights, seed):
+    """For several frames: (a) the kernel's argmax / sim / gathered colour agree with an fp64 evaluation
+    of the SAME theta/phi it consumed (isolates the correlation kernel), and (b) theta/phi/argmax agree
+    with the oracle run end-to-end from the same Lab frame (isolates everything upstream)."""
+    from dvc_amd import ops, synth
+    from dvc_amd.frame import VGG_OUT
+    from oracle import dvc_oracle as O
+    from utils.util import feature_normalize, gray2rgb_batch
+    vgg, warp, _ = nets
+    H, W, T = 216, 384, 1e-10
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
+    fr = synth.synth_lab(seed, H, W)
+    fB = vgg(ops.lab2rgb(IB.cuda(), l_offset=50.0), VGG_OUT)
+    fA = vgg(gray2rgb_batch(fr.cuda()[:, 0:1]), VGG_OUT)
+    y, sim, tp = warp(IB.cuda(), *[feature_normalize(t) for t in fA[1:]], *[feature_normalize(t) for t in fB[1:]],
+                      temperature=T, return_taps=True)
+    th, ph = tp["theta"][0].double(), tp["phi"][0].double()
+    f = th.t() @ ph                                   # 5184 x 5184 fp64 on the device (test-only torch op)
+    top2 = torch.topk(f, 2, dim=-1)
+    gap = top2[0][:, 0] - top2[0][:, 1]
+    amax_k = tp["argmax"][0].long()
+    dis = amax_k != top2[1][:, 0]
+    blab = ops.avgpool4x4(IB.cuda()).view(3, -1)
+    y_k = tp["y_small"][0].view(3, -1)
+    y_from_amax = blab[:, amax_k]
+    colour_bad = ((y_k - y_from_amax).abs().max(0)[0] > 1e-3)
+    sim_err = (tp["sim_small"].view(-1).double() - top2[0][:, 0]).abs().max().item()
+    report(f"corr self-consistency seed={seed}: argmax!=fp64 on {int(dis.sum())} rows (max gap among them "
+           f"{gap[dis].max().item() if dis.any() else 0:.2e}); colour!=blab[argmax] on {int(colour_bad.sum())} rows "
+           f"(gaps {gap[colour_bad][:5].tolist()}); sim_err={sim_err:.2e}")
+    assert sim_err < 2e-6
+    assert (gap[dis] < 1e-5).all()
+    assert (gap[colour_bad] < 1e-5).all()            # softmax one-hot must sit on the kernel's own argmax
+    taps = {}
+    with torch.no_grad():
+        fB_o = O.exemplar_features(IB, weights[0])
+        O.warp_color(fr[:, 0:1], IB, fB_o, weights[0], weights[1], temperature=T, taps=taps)
+    th_err = (tp["theta"].cpu() - taps["theta"]).abs().max().item()
+    ph_err = (tp["phi"].cpu() - taps["phi"]).abs().max().item()
+    ogap = taps["top2"][0, :, 0] - taps["top2"][0, :, 1]
+    odis = tp["argmax"][0].cpu().long() != taps["argmax"][0]
+    report(f"corr vs oracle seed={seed}: theta_err={th_err:.2e} phi_err={ph_err:.2e} argmax disagreements "
+           f"{int(odis.sum())} (max gap {ogap[odis].max().item() if odis.any() else 0:.2e})")
+    assert th_err < 2e-5 and ph_err < 2e-5
+    assert (ogap[odis] < 1e-4).all()
+
+
 def test_warpnet_exemplar_cache_is_bit_identical(nets, weights):
     from dvc_amd import synth
     warp = nets[1]
