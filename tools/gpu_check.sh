@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 (rocminfo | grep -E "Marketing Name|gfx9" | sort | uniq -c; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket") > gpurun_out/box.txt 2>&1
 if [[ $what == all || $what == tests ]]; then
   rm -f gpurun_out/test_report.txt
-  timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider ${PYTEST_ARGS} > gpurun_out/pytest_gpu.log 2>&1
+  timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider ${PYTEST_K:+-k "$PYTEST_K"} > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
   tail -n 40 gpurun_out/pytest_gpu.log
   timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
