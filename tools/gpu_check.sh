@@ -23,7 +23,7 @@ if [[ $what == all || $what == bench ]]; then
 fi
 if [[ $what == all || $what == prof ]]; then
   rm -rf gpurun_out/prof
-  timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o trace -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o trace -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err
   echo "prof rc=$?"; cat gpurun_out/prof_bench.json
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
   [[ -n "$f" ]] && head -n 40 "$f"
