@@ -37,6 +37,10 @@ CORR_BYTES = 4.0 * (2 * P * C + 3 * P + 3 * P + P)      # 10.76 MB compulsory tr
 PATH_FLOPS = 348.4e9                                     # minimal whole-path FLOPs / frame
 PEAK_F32_MFMA_TFLOPS = 157.3                             # MI355X_MICROARCH.md, fp32 matrix
 PEAK_HBM_GBS = 8000.0
+# PMC-measured HBM traffic of one corr_fwd_kernel launch at P=5184 (profiles/r01_pmc_summary.md):
+# 81.8 MB read + 3.3 MB written vs 10.76 MB compulsory (phi is re-streamed through the per-XCD L2s)
+CORR_TRAFFIC_BYTES = 85.1e6
+CORR_TRAFFIC_SOURCE = "profiles/r01_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
 
 
 def log(*a):
@@ -178,7 +182,10 @@ def main():
         achieved = CORR_FLOPS / t_corr / 1e12
         roof = {"kernel": "corr_fwd_kernel (+corr_merge_kernel)", "bound": "mfma",
                 "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                # HBM bytes per launch from the separate rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE,
+                # gfx950 correction per MI355X_MICROARCH.md); measured offline, see profiles/*_pmc_summary.md
+                "traffic": CORR_TRAFFIC_BYTES, "traffic_source": CORR_TRAFFIC_SOURCE,
                 "avg_launch_us": round(t_corr * 1e6, 2),
                 "hbm_view": {"achieved": round(CORR_BYTES / t_corr / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": round(CORR_BYTES / t_corr / 1e9 / PEAK_HBM_GBS, 5),

@@ -1,0 +1,67 @@
+"""Copy the judged profile summaries from gpurun_out/ (scratch) into profiles/ (tracked).
+    python tools/summarize_profiles.py r01
+Produces profiles/<round>_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py`),
+profiles/<round>_bench_line.json (the JSON line printed under the profiler) and
+profiles/<round>_pmc_summary.md (derived metrics from the separate --pmc passes)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+os.makedirs(P, exist_ok=True)
+if os.path.exists(os.path.join(G, "prof", "trace_kernel_stats.csv")):
+    shutil.copy(os.path.join(G, "prof", "trace_kernel_stats.csv"), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
+    shutil.copy(os.path.join(G, "prof_bench.json"), os.path.join(P, f"{tag}_bench_line_under_profiler.json"))
+if os.path.exists(os.path.join(G, "bench.json")):
+    shutil.copy(os.path.join(G, "bench.json"), os.path.join(P, f"{tag}_bench_line.json"))
+if os.path.exists(os.path.join(G, "tune_conv.json")):
+    shutil.copy(os.path.join(G, "tune_conv.json"), os.path.join(P, f"{tag}_conv_layer_sweep.json"))
+if os.path.exists(os.path.join(G, "box.txt")):
+    shutil.copy(os.path.join(G, "box.txt"), os.path.join(P, f"{tag}_box.txt"))
+
+
+def load(path):
+    return list(csv.DictReader(open(path))) if os.path.exists(path) else []
+
+
+dur = collections.defaultdict(list)
+for r in load(os.path.join(G, "pmc1", "p_kernel_trace.csv")):
+    dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for pm in ("pmc1", "pmc2", "pmc3", "pmc4"):
+    for r in load(os.path.join(G, pm, "p_counter_collection.csv")):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+lines = ["# PMC summary (" + tag + ")", "",
+         "Source: `rocprofv3 --kernel-trace --pmc ...` in four separate passes over `tools/prof_kernels.py` "
+         "(corr at P=5184, representative conv layers); counters averaged over the launches of each kernel.",
+         "`GRBM_GUI_ACTIVE` is summed over the 8 XCDs (divide by 8 for cycles); `SQ_WAVE_CYCLES`/`SQ_WAIT_*`/"
+         "`SQ_ACTIVE_INST_ANY` count quad-cycles (x4). `FETCH_SIZE`/`WRITE_SIZE` are KiB; per "
+         "MI355X_MICROARCH.md the gfx950 FETCH_SIZE counts 64 B per 128-B request, so read bytes = 2 x FETCH_SIZE.",
+         "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles).", "",
+         "| kernel | us | clock GHz | waves | MFMA util | per-wave kcycles: alive / own-MFMA / active / wait-inst / wait-any | VALU/wave | LDS bank-conflict cyc | HBM read MB (2xFETCH) | HBM write MB |",
+         "|---|---|---|---|---|---|---|---|---|---|"]
+for k, v in agg.items():
+    if "conv_mfma" not in k and "corr_fwd" not in k:
+        continue
+    c = {n: sum(x) / len(x) for n, x in v.items()}
+    if "GRBM_GUI_ACTIVE" not in c:
+        continue
+    us = sum(dur[k]) / max(len(dur[k]), 1)
+    cyc = c["GRBM_GUI_ACTIVE"] / 8
+    w = c["SQ_WAVES"]
+    lines.append("| `%s` | %.0f | %.2f | %d | %.1f%% | %.0f / %.0f / %.0f / %.0f / %.0f | %.0f | %.0f | %.1f | %.1f |" % (
+        k.replace("void ", "").replace("(ConvKArgs)", "").replace("(CorrArgs)", ""), us, cyc / us / 1e3, w,
+        100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), c["SQ_WAVE_CYCLES"] * 4 / w / 1e3,
+        c["SQ_VALU_MFMA_BUSY_CYCLES"] / w / 1e3, c["SQ_ACTIVE_INST_ANY"] * 4 / w / 1e3,
+        c["SQ_WAIT_INST_ANY"] * 4 / w / 1e3, c.get("SQ_WAIT_ANY", 0) * 4 / w / 1e3, c.get("SQ_INSTS_VALU", 0) / w,
+        c.get("SQ_LDS_BANK_CONFLICT", 0), 2 * c.get("FETCH_SIZE", 0) / 1024, c.get("WRITE_SIZE", 0) / 1024))
+if len(lines) > 9:
+    open(os.path.join(P, f"{tag}_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[-8:]))
+print("profiles/:", sorted(os.listdir(P)))
