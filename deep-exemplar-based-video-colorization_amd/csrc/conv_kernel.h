@@ -30,6 +30,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CONV_EPT_GEN 12  // staged input elements per thread in the run-time-geometry variant
+#define CONV_MAX_AFFINE_CIN 1024  // static LDS affine table of the compile-time-geometry variants
 
 struct ConvKArgs {
     const float* x;
@@ -68,6 +69,15 @@ static const ConvCfg kConvCfgs[5] = {
 // (72 x 64 cycles) is long enough to cover the global-load latency of the next chunk's prefetch
 __host__ __device__ constexpr int conv_ck(int ks, int tiles_per_wave, bool gen) {
     return ks == 3 ? ((tiles_per_wave == 1 && !gen) ? 16 : 8) : 16;
+}
+// LDS buffer sizes (floats).  Both are padded so that the staging stores are unconditional (no exec-mask
+// branches inside the chunk loop): threads without an input element write a dummy slot at the end of the
+// patch buffer, and every weight float4 slot q < WPT*256 exists.
+__host__ __device__ constexpr int conv_xs_floats(int ck, int ih_t, int iw_p) {
+    return ((ck * ih_t * iw_p + 3) & ~3) + 4;
+}
+__host__ __device__ constexpr int conv_ws_floats(int ck, int kk, int mt) {
+    return ((ck * kk * (mt / 4) + 255) / 256) * 256 * 4;
 }
 // LDS row pitch: rows of one N-tile must land on disjoint bank ranges for ds_read_b32 (32 banks):
 // pitch == tw (mod 32) for tw in {16, 8}; any pitch >= width for tw == 32.
@@ -115,7 +125,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 }
 
 template <int WM, int WN, int RM, int RN, int TW, int KS, int DIL, bool GEN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a) {
     constexpr int NT = 64 * WM * WN;
     constexpr int MT = 32 * WM * RM;
     constexpr int RPT = 32 / TW;  // rows per 32-pixel N-tile
@@ -138,12 +148,28 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     const int plane = IH_T * IW_P;
     const int tile_elems = IH_T * IW_T;
     const int total = CK * tile_elems;
-    const int xs_floats = (CK * plane + 3) & ~3;
+    const int xs_floats = conv_xs_floats(CK, IH_T, IW_P);
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;
-    float* ws = smem + xs_floats;
-    float* aff = ws + CK * KK * MT;  // [2][cin_pad] per-channel scale / shift of this image
+    // LDS: two input-patch buffers and two weight-slice buffers (double buffering: chunk c+1 is written
+    // while chunk c is read, one barrier per chunk) + the per-channel affine table.  For the
+    // compile-time-geometry variants these are FOUR DISTINCT static arrays: only then can alias analysis
+    // prove that the staging stores into one buffer do not touch the MFMA chain's reads of the other,
+    // which is what allows the scheduler to interleave the two streams.
+    constexpr int ws_floats = conv_ws_floats(CK, KK, MT);
+    constexpr int C_XS = GEN ? 4 : conv_xs_floats(CK, C_IH, C_IWP);
+    constexpr int C_WS = GEN ? 4 : ws_floats;
+    constexpr int AFF_MAX = GEN ? 4 : 2 * (CONV_MAX_AFFINE_CIN + 16);
+    __shared__ __attribute__((aligned(16))) float s_xs0[C_XS];
+    __shared__ __attribute__((aligned(16))) float s_xs1[C_XS];
+    __shared__ __attribute__((aligned(16))) float s_ws0[C_WS];
+    __shared__ __attribute__((aligned(16))) float s_ws1[C_WS];
+    __shared__ __attribute__((aligned(16))) float s_aff[AFF_MAX];
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // GEN only
+    float* const xsb0 = GEN ? smem : s_xs0;
+    float* const xsb1 = GEN ? smem + xs_floats : s_xs1;
+    float* const wsb0 = GEN ? smem + 2 * xs_floats : s_ws0;
+    float* const wsb1 = GEN ? smem + 2 * xs_floats + ws_floats : s_ws1;
+    float* const aff = GEN ? smem + 2 * xs_floats + 2 * ws_floats : s_aff;  // [2][cin_pad + CK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -160,71 +186,74 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     const float in_slope = a.in_prelu ? *a.in_slope_ptr : 0.f;
     const int vy0 = oy0 * stride - a.pad, vx0 = ox0 * stride - a.pad;
 
-    // ---- per-thread staging plan (identical for every channel chunk): element e = tid + t*NT of the
-    // [CK][IH_T][IW_T] patch -> offset inside one stored channel plane (-1: reads zero, -2: no element)
-    int goff[EPT];
+    // ---- per-thread staging plan, computed once (identical for every channel chunk).
+    // x element e = tid + t*NT of the [CK][IH_T][IW_T] patch:
+    //   gofs[t]  offset from the chunk's first channel plane (c*HW + y*W + x), -1 = reads zero,
+    //            -2 = no such element
+    //   lofs[t]  (channel-in-chunk << 20) | LDS float offset
+    // weight float4 q = tid + i*NT of the [CK*KK][MT] slice:  wofs[i] = row*Cout + m0 + col (or -1)
+    int gofs[EPT], lofs[EPT];
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
         int e = tid + t * NT;
         if (e < total) {
-            int rem = e % tile_elems;
+            int c = e / tile_elems;
+            int rem = e - c * tile_elems;
             int iy = rem / IW_T, ix = rem - iy * IW_T;
-            goff[t] = stored_offset(a, vy0 + iy, vx0 + ix);
+            int g = stored_offset(a, vy0 + iy, vx0 + ix);
+            gofs[t] = g >= 0 ? c * HWi + g : -1;
+            lofs[t] = (c << 20) | (c * plane + iy * IW_P + ix);
         } else {
-            goff[t] = -2;
+            gofs[t] = -2;
+            lofs[t] = xs_floats - 1;  // dummy slot
         }
     }
     constexpr int nq = CK * KK * ROW4;
-    const int grow_end = a.Cin * KK;
+    int wofs[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        int q = tid + i * NT;
+        int row = q / ROW4, col = (q % ROW4) * 4;
+        wofs[i] = (q < nq && m0 + col < a.Cout) ? row * a.Cout + m0 + col : -1;
+    }
+    const int nchunks = (a.Cin + CK - 1) / CK;
+    const bool ragged = (a.Cin % CK) != 0;  // only then can a staged channel lie beyond Cin
 
     float xr[EPT];
     float4 wr[WPT];
-    // issue the global loads of one channel chunk into registers (no dependent use -> all in flight)
-    auto issue = [&](int c0) {
+    // issue the global loads of chunk `ci` into registers (nothing consumes them until commit)
+    auto issue = [&](int ci) {
+        const int c0 = ci * CK;
+        const int xbase = c0 * HWi;
+        const int wbase = c0 * KK * a.Cout;
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
-            int ch = c0 + (tid + t * NT) / tile_elems;
-            bool ok = goff[t] >= 0 && ch < a.Cin;
-            xr[t] = xn[ok ? (unsigned)(ch * HWi + goff[t]) : 0u];
+            bool ok = gofs[t] >= 0 && (!ragged || c0 + (lofs[t] >> 20) < a.Cin);
+            xr[t] = xn[ok ? (unsigned)(xbase + gofs[t]) : 0u];
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            int q = tid + i * NT;
-            int row = q / ROW4, col = (q % ROW4) * 4;
-            int grow = c0 * KK + row;
-            bool ok = q < nq && grow < grow_end && m0 + col < a.Cout;
-            wr[i] = *reinterpret_cast<const float4*>(a.w + (ok ? (unsigned)(grow * a.Cout + m0 + col) : 0u));
+            bool ok = wofs[i] >= 0 && (!ragged || c0 + (tid + i * NT) / (KK * ROW4) < a.Cin);
+            wr[i] = *reinterpret_cast<const float4*>(a.w + (ok ? (unsigned)(wbase + wofs[i]) : 0u));
         }
     };
-    // transform + write the prefetched chunk into LDS
-    auto commit = [&](int c0) {
+    // transform + write the prefetched chunk `ci` into LDS buffer `buf`
+    auto commit = [&](int ci, float* xs, float* ws) {
+        const int c0 = ci * CK;
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
-            if (goff[t] != -2) {
-                int e = tid + t * NT;
-                int c = e / tile_elems;
-                int rem = e - c * tile_elems;
-                int iy = rem / IW_T, ix = rem - iy * IW_T;
-                int ch = c0 + c;
-                bool ok = goff[t] >= 0 && ch < a.Cin;
-                float v = 0.f;
-                if (ok) {
-                    v = xr[t];
-                    if (affine) v = v * aff[ch] + aff[a.cin_pad + ch];
-                    if (a.in_prelu) v = v >= 0.f ? v : v * in_slope;
-                }
-                xs[c * plane + iy * IW_P + ix] = v;
-            }
+            const int ch = c0 + (lofs[t] >> 20);
+            const bool ok = gofs[t] >= 0 && (!ragged || ch < a.Cin);
+            float v = xr[t];
+            if (affine) v = v * aff[ch] + aff[a.cin_pad + CK + ch];   // table is zero-padded past Cin
+            if (a.in_prelu) v = v >= 0.f ? v : v * in_slope;
+            xs[lofs[t] & 0xFFFFF] = ok ? v : 0.f;   // unconditional store (dummy slot if no element)
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            int q = tid + i * NT;
-            if (q < nq) {
-                int row = q / ROW4, col = (q % ROW4) * 4;
-                int grow = c0 * KK + row;
-                bool ok = grow < grow_end && m0 + col < a.Cout;
-                *reinterpret_cast<float4*>(ws + row * MT + col) = ok ? wr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            const int q = tid + i * NT;
+            const bool ok = wofs[i] >= 0 && (!ragged || c0 + q / (KK * ROW4) < a.Cin);
+            *reinterpret_cast<float4*>(ws + q * 4) = ok ? wr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -232,15 +261,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
     if (affine) {
         const float* scn = a.in_scale + (long)n * a.Cin;
         const float* shn = a.in_shift + (long)n * a.Cin;
-        for (int i = tid; i < a.Cin; i += NT) {
-            aff[i] = scn[i];
-            aff[a.cin_pad + i] = shn[i];
+        for (int i = tid; i < a.cin_pad + CK; i += NT) {   // (+CK: a ragged last chunk indexes past Cin)
+            aff[i] = i < a.Cin ? scn[i] : 0.f;
+            aff[a.cin_pad + CK + i] = i < a.Cin ? shn[i] : 0.f;
         }
         __syncthreads();
     }
-    commit(0);
+    commit(0, xsb0, wsb0);
+    issue(min(1, nchunks - 1));
     __syncthreads();
 
+    // tot: running sum; acc: one chunk's MFMA chain.  Flushing per chunk keeps every fp32 chain short
+    // (CK*ks*ks terms) and makes the total a sum of Cin/CK partials — blocked summation.
     f32x16 tot[RM][RN], acc[RM][RN];
 #pragma unroll
     for (int i = 0; i < RM; ++i)
@@ -249,18 +281,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
 
-    const float* xb[RN];  // this lane's pixel in the LDS patch (tap 0, channel `hi`)
+    int xoff[RN];  // this lane's pixel in the LDS patch (tap 0, channel `hi`), float offset
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
         int t = wn * RN + j;
         int r = l31 / TW, c = l31 % TW;
-        xb[j] = xs + hi * plane + ((t * RPT + r) * stride) * IW_P + c * stride;
+        xoff[j] = hi * plane + ((t * RPT + r) * stride) * IW_P + c * stride;
     }
-    const float* wb = ws + hi * KK * MT + wm * RM * 32 + l31;
+    const int woff = hi * KK * MT + wm * RM * 32 + l31;
 
-    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
-        const bool has_next = c0 + CK < a.Cin;
-        if (has_next) issue(c0 + CK);  // global latency hides under this chunk's MFMAs
+    // One chunk: write chunk ci+1 (already in registers) into the OTHER LDS buffer, refill the
+    // registers with chunk ci+2, run chunk ci's MFMA chain.  Single basic block; the scheduler is
+    // asked (sched_group_barrier) to spread the staging instructions between the MFMAs.  Past the
+    // last chunk the clamped indices re-stage the last chunk: harmless.
+    auto chunk = [&](int ci, const float* xs, const float* ws, float* xs_next, float* ws_next) {
+        commit(min(ci + 1, nchunks - 1), xs_next, ws_next);
+        issue(min(ci + 2, nchunks - 1));
+        const float* wb = ws + woff;
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -277,7 +314,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
 #pragma unroll
                 for (int i = 0; i < RM; ++i) av[i] = wb[(kk * KK + tap) * MT + i * 32];
 #pragma unroll
-                for (int j = 0; j < RN; ++j) bv[j] = xb[j][kk * plane + toff];
+                for (int j = 0; j < RN; ++j) bv[j] = xs[xoff[j] + kk * plane + toff];
 #pragma unroll
                 for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -285,15 +322,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvKArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
         }
+        // interleave request: per MFMA two LDS reads and a few VALU; every 4th MFMA one global load and
+        // one LDS write of the staging stream
+#pragma unroll
+        for (int i = 0; i < KK * (CK / 2) * RM * RN; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
+            if ((i & 3) == 0) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+            }
+        }
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
             for (int j = 0; j < RN; ++j) tot[i][j] += acc[i][j];
-        if (has_next) {
-            __syncthreads();  // every wave finished reading this chunk from LDS
-            commit(c0 + CK);
-            __syncthreads();
-        }
+        __syncthreads();  // chunk ci+1 is visible in LDS; everyone is done reading chunk ci
+    };
+    for (int ci = 0; ci < nchunks; ci += 2) {
+        chunk(ci, xsb0, wsb0, xsb1, wsb1);
+        if (ci + 1 < nchunks) chunk(ci + 1, xsb1, wsb1, xsb0, wsb0);
     }
 
     // ---- epilogue: bias + residual + activation, coalesced NCHW store

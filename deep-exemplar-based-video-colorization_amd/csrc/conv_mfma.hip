@@ -113,8 +113,12 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     const int ck = conv_ck(d->ksize, c.rm * c.rn, gen);
     geom(cfg, &a.IH_T, &a.IW_T);
     a.IW_P = conv_pitch(tw, a.IW_T, d->stride);
-    const int xs_floats = (ck * a.IH_T * a.IW_P + 3) & ~3;
-    size_t lds = sizeof(float) * ((size_t)xs_floats + (size_t)ck * a.ks * a.ks * mt + (in_scale ? 2 * (size_t)a.cin_pad : 0));
+    const int xs_floats = conv_xs_floats(ck, a.IH_T, a.IW_P);
+    // run-time-geometry kernels carve everything from dynamic LDS; the others use static arrays
+    size_t lds = gen ? sizeof(float) * (2 * (size_t)xs_floats + 2 * (size_t)conv_ws_floats(ck, a.ks * a.ks, mt) +
+                                        (in_scale ? 2 * (size_t)(a.cin_pad + ck) : 0))
+                     : 0;
+    if (!gen && in_scale) DVC_REQUIRE(d->Cin <= CONV_MAX_AFFINE_CIN, "dvc_conv2d: fused input affine supports Cin <= %d", CONV_MAX_AFFINE_CIN);
     DVC_REQUIRE(lds <= 160 * 1024, "dvc_conv2d: LDS tile too large (%zu bytes)", lds);
     dim3 grid(cdiv(OW, tw) * cdiv(OH, ph), cdiv(d->Cout, mt), d->N);
     hipStream_t s = (hipStream_t)stream;
