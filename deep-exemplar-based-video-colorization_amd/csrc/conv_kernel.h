@@ -30,7 +30,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CONV_EPT_GEN 12  // staged input elements per thread in the run-time-geometry variant
-#define CONV_MAX_AFFINE_CIN 1024  // static LDS affine table of the compile-time-geometry variants
+#define CONV_MAX_AFFINE_CIN 512  // static LDS affine table of the compile-time-geometry variants
 
 struct ConvKArgs {
     const float* x;
@@ -51,6 +51,9 @@ struct ConvKArgs {
     long x_bs, y_bs, res_bs;
     int IH_T, IW_T, IW_P;  // LDS input-patch geometry (authoritative only for GEN kernels)
     int cin_pad;           // Cin rounded up to a multiple of 4
+    int split;             // split-K factor S (1 = off): blockIdx.z = n*S + s, raw partial sums go to `part`
+    int chunks_per_split;
+    float* part;           // [S][N][Cout][OH][OW]
 };
 
 struct ConvCfg {
@@ -65,10 +68,10 @@ static const ConvCfg kConvCfgs[5] = {
     {2, 2, 1, 1},  // 4: 64 co x 2 N-tiles
 };
 
-// input channels per LDS chunk: one-tile-per-wave configurations take 16 so that a chunk's MFMA chain
-// (72 x 64 cycles) is long enough to cover the global-load latency of the next chunk's prefetch
+// input channels per LDS chunk (8 keeps the double-buffered LDS footprint small enough for >= 2
+// workgroups per CU; occupancy, not chunk length, hides the global-load latency)
 __host__ __device__ constexpr int conv_ck(int ks, int tiles_per_wave, bool gen) {
-    return ks == 3 ? ((tiles_per_wave == 1 && !gen) ? 16 : 8) : 16;
+    return ks == 3 ? 8 : 16;
 }
 // LDS buffer sizes (floats).  Both are padded so that the staging stores are unconditional (no exec-mask
 // branches inside the chunk loop): threads without an input element write a dummy slot at the end of the
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
     const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
     const int ox0 = bx * TW, oy0 = by * PH;
     const int m0 = blockIdx.y * MT;
-    const int n = blockIdx.z;
+    const int n = blockIdx.z / a.split, ksplit = blockIdx.z % a.split;
     const int HWi = a.H * a.W;  // tensors are < 2^31 elements
     const float* xn = a.x + (long)n * a.x_bs;
     const bool affine = a.in_scale != nullptr;
@@ -216,7 +219,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
         int row = q / ROW4, col = (q % ROW4) * 4;
         wofs[i] = (q < nq && m0 + col < a.Cout) ? row * a.Cout + m0 + col : -1;
     }
-    const int nchunks = (a.Cin + CK - 1) / CK;
+    const int nchunks_all = (a.Cin + CK - 1) / CK;
+    const int c_begin = ksplit * a.chunks_per_split;
+    const int nchunks = min(nchunks_all, c_begin + a.chunks_per_split);  // this block walks [c_begin, nchunks)
     const bool ragged = (a.Cin % CK) != 0;  // only then can a staged channel lie beyond Cin
 
     float xr[EPT];
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
         }
     };
 
-    issue(0);
+    issue(c_begin);
     if (affine) {
         const float* scn = a.in_scale + (long)n * a.Cin;
         const float* shn = a.in_shift + (long)n * a.Cin;
@@ -267,8 +272,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
         }
         __syncthreads();
     }
-    commit(0, xsb0, wsb0);
-    issue(min(1, nchunks - 1));
+    commit(c_begin, xsb0, wsb0);
+    issue(min(c_begin + 1, nchunks - 1));
     __syncthreads();
 
     // tot: running sum; acc: one chunk's MFMA chain.  Flushing per chunk keeps every fp32 chain short
@@ -340,12 +345,33 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
             for (int j = 0; j < RN; ++j) tot[i][j] += acc[i][j];
         __syncthreads();  // chunk ci+1 is visible in LDS; everyone is done reading chunk ci
     };
-    for (int ci = 0; ci < nchunks; ci += 2) {
+    for (int ci = c_begin; ci < nchunks; ci += 2) {
         chunk(ci, xsb0, wsb0, xsb1, wsb1);
         if (ci + 1 < nchunks) chunk(ci + 1, xsb1, wsb1, xsb0, wsb0);
     }
 
-    // ---- epilogue: bias + residual + activation, coalesced NCHW store
+    // ---- epilogue
+    if (a.split > 1) {  // split-K: raw partial sums; bias / residual / activation happen in the reduce kernel
+        const long OHW = (long)a.OH * a.OW;
+        float* pn = a.part + ((long)ksplit * a.N + n) * a.Cout * OHW;
+        const int pr = l31 / TW, pc = l31 % TW;
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            int t = wn * RN + j;
+            int oy = oy0 + t * RPT + pr, ox = ox0 + pc;
+            if (oy >= a.OH || ox >= a.OW) continue;
+            long pix = (long)oy * a.OW + ox;
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int co = m0 + (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (co < a.Cout) pn[(long)co * OHW + pix] = tot[i][j][r];
+                }
+        }
+        return;
+    }
+    // bias + residual + activation, coalesced NCHW store
     const float slope = a.act_slope_ptr ? *a.act_slope_ptr : a.act_slope;
     const long OHW = (long)a.OH * a.OW;
     float* yn = a.y + (long)n * a.y_bs;

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvc_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -21,7 +21,7 @@ class DvcConvDesc(ctypes.Structure):
         ("N", c_i32), ("Cin", c_i32), ("H", c_i32), ("W", c_i32),
         ("Cout", c_i32), ("ksize", c_i32), ("stride", c_i32), ("dil", c_i32),
         ("pad", c_i32), ("pad_mode", c_i32), ("in_up", c_i32), ("in_sub", c_i32),
-        ("act", c_i32), ("act_slope", ctypes.c_float), ("in_prelu", c_i32), ("cfg", c_i32),
+        ("act", c_i32), ("act_slope", ctypes.c_float), ("in_prelu", c_i32), ("cfg", c_i32), ("split_k", c_i32),
         ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("res_batch_stride", c_i64),
     ]
 
@@ -32,7 +32,8 @@ SIGNATURES = {
     "dvc_abi_version": (ctypes.c_int, []),
     "dvc_last_error": (ctypes.c_char_p, []),
     "dvc_conv2d_out_hw": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
-    "dvc_conv2d": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "dvc_conv2d": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                  ctypes.c_size_t, _VP]),
     "dvc_conv1x1_small": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, _VP, _VP]),
     "dvc_instnorm_stats": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, c_i64, ctypes.c_float, _VP, _VP, _VP, _VP]),
     "dvc_affine_act": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,

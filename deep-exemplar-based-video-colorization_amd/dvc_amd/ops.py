@@ -37,6 +37,7 @@ def _need(t, name):
 
 
 conv_record = None   # set to a list to log every conv2d launch (tools/tune_conv.py)
+CONV_WORKSPACE_BYTES = 32 << 20   # split-K scratch: 4 x the largest under-filled layer output
 
 
 def pack_conv_weight(w):
@@ -54,7 +55,7 @@ def conv_out_hw(H, W, ksize=3, stride=1, dil=1, pad=1, in_up=1, in_sub=1):
 
 def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1,
            act=ACT_NONE, act_slope=0.0, act_slope_t=None, in_scale=None, in_shift=None, in_slope_t=None,
-           residual=None, out=None, out_batch_stride=0, cfg=-1):
+           residual=None, out=None, out_batch_stride=0, cfg=-1, split_k=0):
     """dvc_conv2d.  x: [N,Cin,H,W]; w_packed: [Cin, k*k, Cout].  `out` may be a channel slice view's
     base pointer tensor (pass `out_batch_stride` in elements)."""
     lib = _lib.load()
@@ -69,15 +70,17 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
     if out is None:
         out = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
     d = DvcConvDesc(N, Cin, H, W, Cout, ksize, stride, dil, pad, pad_mode, in_up, in_sub, act,
-                    float(act_slope), 1 if in_slope_t is not None else 0, cfg, 0, out_batch_stride, 0)
+                    float(act_slope), 1 if in_slope_t is not None else 0, cfg, split_k, 0, out_batch_stride, 0)
     if residual is not None:
         assert tuple(residual.shape) == (N, Cout, OH, OW), (residual.shape, (N, Cout, OH, OW))
     if conv_record is not None:
         conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=ksize, stride=stride, dil=dil, pad=pad,
                                 pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, affine=in_scale is not None,
                                 in_prelu=in_slope_t is not None, residual=residual is not None, act=act))
+    ws = _workspace(x.device, CONV_WORKSPACE_BYTES, "conv")
     rc = lib.dvc_conv2d(ctypes.byref(d), _p(x), _p(w_packed), _p(bias), _p(in_scale), _p(in_shift),
-                        _p(in_slope_t), _p(act_slope_t), _p(residual), _p(out), _stream())
+                        _p(in_slope_t), _p(act_slope_t), _p(residual), _p(out),
+                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     _lib.check(rc, "dvc_conv2d")
     return out
 
@@ -210,8 +213,8 @@ def corr_prepare(t_raw, eps=EPS64):
 _ws_cache = {}
 
 
-def _workspace(device, nbytes):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+def _workspace(device, nbytes, tag="corr"):
+    key = (tag, device.index, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, device=device, dtype=torch.uint8)

@@ -27,7 +27,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 1
+#define DVC_ABI_VERSION 2
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -53,6 +53,10 @@ const char* dvc_last_error(void);
  * position (reflect pad, applied in the virtual domain exactly like ReflectionPad2d after Upsample).
  *
  * Weights are pre-packed as w_packed[ci][ky*ks+kx][co] (co contiguous), Cout % 4 == 0.
+ *
+ * Layers too small to fill the 1024 SIMDs are split over input-channel chunks (split-K): partial sums
+ * go to `workspace` ([S][N][Cout][OH][OW] floats) and a second tiny kernel adds them in a fixed order and
+ * applies bias / residual / activation.  Without a workspace split-K is off.
  */
 enum { DVC_ACT_NONE = 0, DVC_ACT_RELU = 1, DVC_ACT_PRELU = 2, DVC_ACT_LEAKY = 3, DVC_ACT_TANH128 = 4 };
 enum { DVC_PAD_ZERO = 0, DVC_PAD_REFLECT = 1 };
@@ -71,6 +75,7 @@ typedef struct DvcConvDesc {
     float   act_slope;          /* PReLU/LeakyReLU slope when act_slope_ptr == NULL */
     int32_t in_prelu;           /* apply PReLU (slope *in_slope_ptr) to the affine-transformed input */
     int32_t cfg;                /* tile configuration; -1 = choose automatically */
+    int32_t split_k;            /* 0 = automatic, 1 = off, 2..4 = forced (needs a workspace) */
     int64_t x_batch_stride;     /* elements; 0 => Cin*H*W */
     int64_t y_batch_stride;     /* elements; 0 => Cout*OH*OW  (lets y be a channel slice) */
     int64_t res_batch_stride;   /* elements; 0 => Cout*OH*OW */
@@ -84,7 +89,9 @@ int dvc_conv2d(const DvcConvDesc* d,
                const float* in_scale /* [N*Cin] or NULL */, const float* in_shift /* [N*Cin] or NULL */,
                const float* in_slope_ptr /* device scalar, used when in_prelu */,
                const float* act_slope_ptr /* device scalar or NULL */,
-               const float* residual /* or NULL */, float* y, dvcStream stream);
+               const float* residual /* or NULL */, float* y,
+               void* workspace /* or NULL: scratch for split-K partial sums */, size_t workspace_bytes,
+               dvcStream stream);
 
 /* conv 1x1 with tiny Cout (<= 4) + optional tanh*128: ColorVidNet.conv10_ab, ColorVidNet.py:142-144.
  * w is the unpacked [Cout][Cin] matrix. */

@@ -33,12 +33,12 @@ def test_argument_validation_without_gpu():
     """Validation errors are reported through the return code + dvc_last_error, before any launch."""
     from dvc_amd import _lib
     lib = _lib.load()
-    d = _lib.DvcConvDesc(1, 4, 8, 8, 6, 3, 1, 1, 1, 0, 1, 1, 0, 0.0, 0, -1, 0, 0, 0)   # Cout % 4 != 0
+    d = _lib.DvcConvDesc(1, 4, 8, 8, 6, 3, 1, 1, 1, 0, 1, 1, 0, 0.0, 0, -1, 0, 0, 0, 0)   # Cout % 4 != 0
     one = ctypes.c_void_p(16)
-    rc = lib.dvc_conv2d(ctypes.byref(d), one, one, None, None, None, None, None, None, one, None)
+    rc = lib.dvc_conv2d(ctypes.byref(d), one, one, None, None, None, None, None, None, one, None, 0, None)
     assert rc != 0 and b"multiple of 4" in lib.dvc_last_error()
     oh, ow = ctypes.c_int32(), ctypes.c_int32()
-    d2 = _lib.DvcConvDesc(1, 4, 27, 45, 8, 3, 2, 1, 1, 1, 1, 1, 0, 0.0, 0, -1, 0, 0, 0)
+    d2 = _lib.DvcConvDesc(1, 4, 27, 45, 8, 3, 2, 1, 1, 1, 1, 1, 0, 0.0, 0, -1, 0, 0, 0, 0)
     assert lib.dvc_conv2d_out_hw(ctypes.byref(d2), ctypes.byref(oh), ctypes.byref(ow)) == 0
     assert (oh.value, ow.value) == (14, 23)
 

@@ -117,6 +117,33 @@ def test_conv2d(ops, case, cfg):
     assert e < 2e-5, (name, cfg, e)  # fp32 accumulation over <= 2304 terms
 
 
+@pytest.mark.parametrize("split_k", [1, 2, 3, 4])
+def test_conv2d_split_k(ops, split_k):
+    """Split-K (partial sums + fixed-order reduce) gives the same result as the single-pass kernel, with
+    bias / residual / activation / input affine, a channel-slice destination and batch 2."""
+    g = torch.Generator().manual_seed(17)
+    N, Cin, Cout, H, W = 2, 96, 64, 27, 48
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    sc, sh = torch.rand(N * Cin, generator=g) + 0.5, torch.randn(N * Cin, generator=g) * 0.3
+    res = torch.randn(N, Cout, H, W, generator=g)
+    ref = ref_conv(x, w, b, 3, 1, 2, 2, 0, 1, 1, sc, sh, None, res, 1, 0.0)
+    big = torch.full((N, 80, H, W), 3.0, device="cuda")
+    ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), b.cuda(), dil=2, pad=2, act=1, in_scale=sc.cuda(),
+               in_shift=sh.cuda(), residual=res.cuda(), out=big[:, 8:72], out_batch_stride=80 * H * W,
+               split_k=split_k)
+    y1 = big[:, 8:72].clone()
+    ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), b.cuda(), dil=2, pad=2, act=1, in_scale=sc.cuda(),
+               in_shift=sh.cuda(), residual=res.cuda(), out=big[:, 8:72], out_batch_stride=80 * H * W,
+               split_k=split_k)
+    e = relerr(y1, ref)
+    report(f"conv2d split_k={split_k}: rel_err={e:.3e}")
+    assert e < 2e-5
+    assert torch.equal(y1, big[:, 8:72])                     # deterministic
+    assert (big[:, :8] == 3).all() and (big[:, 72:] == 3).all()
+
+
 def test_conv2d_channel_slice_output(ops):
     """y may be a channel slice of a wider tensor (WarpNet concat, NonlocalNet.py:464)."""
     g = torch.Generator().manual_seed(5)

@@ -66,8 +66,22 @@ for k, (r, count) in uniq.items():
             times[cfg] = e0.elapsed_time(e1) / 8 * 1e3
         except RuntimeError as e:
             times[cfg] = None
+    for sk in (1, 2, 3, 4):
+        def run():
+            ops.conv2d(x, w, b, ksize=r["ksize"], stride=r["stride"], dil=r["dil"], pad=r["pad"],
+                       pad_mode=r["pad_mode"], in_up=r["in_up"], in_sub=r["in_sub"], act=r["act"], act_slope=0.2,
+                       in_scale=sc, in_shift=sh, in_slope_t=sl, residual=res, out=out, cfg=-1, split_k=sk)
+        for _ in range(2):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        times[f"sk{sk}"] = e0.elapsed_time(e1) / 8 * 1e3
     flops = 2.0 * r["N"] * r["Cout"] * OH * OW * r["Cin"] * r["ksize"] ** 2
-    valid = {c: t for c, t in times.items() if t is not None and c >= 0}
+    valid = {c: t for c, t in times.items() if t is not None and isinstance(c, int) and c >= 0}
     best = min(valid, key=valid.get)
     results.append(dict(shape=r, count=count, OH=OH, OW=OW, gflop=flops / 1e9, us=times, best=best,
                         tflops_auto=flops / times[-1] / 1e6, tflops_best=flops / valid[best] / 1e6))
@@ -83,4 +97,4 @@ for d in results[:45]:
     print(f'{d["count"]}x Cin={s["Cin"]:3d} Cout={s["Cout"]:3d} {s["H"]}x{s["W"]}->{d["OH"]}x{d["OW"]} k{s["ksize"]} s{s["stride"]} d{s["dil"]} '
           f'up{s["in_up"]} sub{s["in_sub"]}: auto {d["us"][-1]:.0f}us ({d["tflops_auto"]:.1f} TF) best cfg{d["best"]} '
           f'{d["us"][d["best"]]:.0f}us ({d["tflops_best"]:.1f} TF) all=' + " ".join(
-              f'{c}:{(t if t else 0):.0f}' for c, t in d["us"].items() if c >= 0))
+              f'{c}:{(t if t else 0):.0f}' for c, t in d["us"].items() if c != -1))
