@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="use the static tile cost model instead of first-use timing")
     ap.add_argument("--no-exemplar-cache", action="store_true",
                     help="recompute the exemplar side of WarpNet every frame, as the reference does")
     args = ap.parse_args()
@@ -125,6 +126,7 @@ def main():
     from dvc_amd.frame import ClipColorizer
     from dvc_amd.parallel import broadcast_exemplar
 
+    ops.set_autotune(not args.no_autotune)   # like the reference's cudnn.benchmark = True (test.py:140)
     nets, sd = build_nets(device)
     cc = ClipColorizer(*nets, temperature=1e-10, cache_exemplar=not args.no_exemplar_cache)
     # exemplar: prepared on rank 0, shared once with every rank (RCCL broadcast over xGMI)
@@ -209,6 +211,8 @@ def main():
                                    "recurrence as test.py:68-96",
                        "H": H, "W": W, "temperature": 1e-10, "weights": "synthetic seed 0",
                        "exemplar_side": "recomputed per frame" if args.no_exemplar_cache else "cached per clip",
+                       "conv_tile_choice": "static cost model" if args.no_autotune else
+                       "autotuned on first use during warm-up (cf. cudnn.benchmark=True, test.py:140)",
                        "frames_per_gpu": K, "parallelism": f"frame-chunks x{n_gpus}"},
             "roofline": roof,
             "cpu_baseline": cpu,

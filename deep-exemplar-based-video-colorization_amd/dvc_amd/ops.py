@@ -37,6 +37,25 @@ def _need(t, name):
 
 
 conv_record = None   # set to a list to log every conv2d launch (tools/tune_conv.py)
+
+# ---- autotuning (the analogue of the reference's `cudnn.benchmark = True`, test.py:140): the first
+# time a conv geometry is seen, every (tile configuration, split-K) candidate is timed once on the
+# real tensors and the fastest is cached for the rest of the process.  Off by default (static cost
+# model in the library); `set_autotune(True)` or DVC_AUTOTUNE=1 turns it on.  Tuning synchronises the
+# device, so do it during warm-up, never inside a timed or graph-captured region.
+import os as _os
+_autotune = _os.environ.get("DVC_AUTOTUNE", "0") == "1"
+_tuned = {}
+
+
+def set_autotune(flag=True):
+    global _autotune
+    _autotune = bool(flag)
+
+
+def autotune_table():
+    return dict(_tuned)
+
 CONV_WORKSPACE_BYTES = 32 << 20   # split-K scratch: 4 x the largest under-filled layer output
 
 
@@ -73,6 +92,14 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
                     float(act_slope), 1 if in_slope_t is not None else 0, cfg, split_k, 0, out_batch_stride, 0)
     if residual is not None:
         assert tuple(residual.shape) == (N, Cout, OH, OW), (residual.shape, (N, Cout, OH, OW))
+    if _autotune and cfg == -1 and split_k == 0:
+        key = (N, Cin, H, W, Cout, ksize, stride, dil, pad, pad_mode, in_up, in_sub, in_scale is not None,
+               in_slope_t is not None, residual is not None, act, x.device.index)
+        best = _tuned.get(key)
+        if best is None:
+            best = _tune_conv(lib, d, (x, w_packed, bias, in_scale, in_shift, in_slope_t, act_slope_t, residual, out))
+            _tuned[key] = best
+        d.cfg, d.split_k = best
     if conv_record is not None:
         conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=ksize, stride=stride, dil=dil, pad=pad,
                                 pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, affine=in_scale is not None,
@@ -83,6 +110,37 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     _lib.check(rc, "dvc_conv2d")
     return out
+
+
+def _tune_conv(lib, d, tensors):
+    """Time every (cfg, split_k) candidate for descriptor `d`; returns the fastest pair."""
+    x, w_packed, bias, in_scale, in_shift, in_slope_t, act_slope_t, residual, out = tensors
+    ws = _workspace(x.device, CONV_WORKSPACE_BYTES, "conv")
+    stream = _stream()
+
+    def launch():
+        return lib.dvc_conv2d(ctypes.byref(d), _p(x), _p(w_packed), _p(bias), _p(in_scale), _p(in_shift),
+                              _p(in_slope_t), _p(act_slope_t), _p(residual), _p(out),
+                              ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream)
+
+    best, best_t = (-1, 0), float("inf")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for cfg in range(5):
+        for sk in (1, 2, 3, 4):
+            d.cfg, d.split_k = cfg, sk
+            if launch() != 0:          # configuration does not fit this geometry
+                break
+            launch()
+            e0.record()
+            for _ in range(3):
+                launch()
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if t < best_t:
+                best, best_t = (cfg, sk), t
+    d.cfg, d.split_k = best
+    return best
 
 
 def conv1x1_small(x, w, bias, act=ACT_NONE):
