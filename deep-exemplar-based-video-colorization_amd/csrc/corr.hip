@@ -92,6 +92,8 @@ struct CorrArgs {
     float* part;           // [B][nslot][CORR_NF][P]
     float T, invT, wta_scale;
     int P, ntiles, tiles_per_split, nslot;
+    long long* dbg;        // debug timeline (NULL in production): [workgroup][tile][4] s_memtime stamps of wave 0
+    int dbg_tiles;
 };
 
 #define AS1 __attribute__((address_space(1)))
@@ -221,8 +223,12 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         commit(0, 0);
     }
     __syncthreads();  // (drains the LDS-DMA of the first tile)
+    long long* dbgp = nullptr;
+    if (a.dbg && tid == 0)
+        dbgp = a.dbg + ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * a.dbg_tiles * 4;
     for (int t = t0; t < t1; ++t) {
         const int cur = (t - t0) & 1;
+        if (dbgp && t - t0 < a.dbg_tiles) dbgp[(t - t0) * 4 + 0] = __builtin_amdgcn_s_memtime();
         issue(min(t + 1, t1 - 1), cur ^ 1);  // (the last iteration re-stages its own tile: harmless)
 
         // S^T tile of THIS key tile: 128 dependent MFMAs (K = 256) in 16 segments of 8.  The softmax of
@@ -251,10 +257,13 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
             // that neither can be hoisted / sunk out of its segment by earlier passes
             asm volatile("" : "+v"(acc), "+v"(l), "+v"(y0), "+v"(y1), "+v"(y2));
         }
+        if (dbgp && t - t0 < a.dbg_tiles) dbgp[(t - t0) * 4 + 1] = __builtin_amdgcn_s_memtime();
         finish_tile(acc, t * CORR_KT);
+        if (dbgp && t - t0 < a.dbg_tiles) dbgp[(t - t0) * 4 + 2] = __builtin_amdgcn_s_memtime();
         blp = bl + ((t - t0) % 3) * 256;
         commit(cur ^ 1, (t + 1 - t0) % 3);
         __syncthreads();  // next tile landed (DMA drained / stores visible); this tile's reads done
+        if (dbgp && t - t0 < a.dbg_tiles) dbgp[(t - t0) * 4 + 3] = __builtin_amdgcn_s_memtime();
     }
     // drain: softmax of the last tile
     rescale();
@@ -378,6 +387,15 @@ extern "C" size_t dvc_corr_workspace_bytes(int32_t B, int32_t P) {
     return part + fmax + 256;
 }
 
+// debug hook (not part of the public header): the next dvc_corr_fwd launches record per-tile s_memtime
+// stamps of wave 0 of every workgroup into `buf` ([workgroups][max_tiles][4]); pass NULL to switch off.
+static long long* g_corr_dbg = nullptr;
+static int g_corr_dbg_tiles = 0;
+extern "C" void dvc_debug_corr_timeline(long long* buf, int max_tiles) {
+    g_corr_dbg = buf;
+    g_corr_dbg_tiles = max_tiles;
+}
+
 extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* blab, float temperature,
                             float wta_scale, int32_t B, int32_t C, int32_t h, int32_t w, float* y_small,
                             float* sim_small, float* y_up, float* sim_up, int32_t* argmax,
@@ -393,6 +411,7 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
         DVC_REQUIRE(((reinterpret_cast<uintptr_t>(y_up) | reinterpret_cast<uintptr_t>(sim_up)) & 15) == 0,
                     "dvc_corr_fwd: upsampled outputs must be 16-byte aligned");
     CorrArgs a;
+    a.dbg = g_corr_dbg; a.dbg_tiles = g_corr_dbg_tiles;
     a.theta = theta; a.phi = phi; a.blab = blab;
     a.T = temperature; a.invT = 1.0f / temperature; a.wta_scale = wta_scale; a.P = P;
     int nsplit;
