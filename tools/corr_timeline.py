@@ -1,0 +1,47 @@
+"""Debug: per-tile phase timeline of corr_fwd_kernel (wave 0 of every workgroup), P=5184."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deep-exemplar-based-video-colorization_amd"))
+import torch  # noqa: E402
+
+from dvc_amd import _lib, ops  # noqa: E402
+
+lib = _lib.load()
+lib.dvc_debug_corr_timeline.restype = None
+lib.dvc_debug_corr_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
+dev = torch.device("cuda")
+g = torch.Generator().manual_seed(1)
+h, w = 54, 96
+P = h * w
+th = ops.corr_prepare(torch.randn(1, 256, P, generator=g).to(dev))
+ph = ops.corr_prepare(torch.randn(1, 256, P, generator=g).to(dev))
+bl = torch.randn(1, 3, P, generator=g).to(dev)
+for _ in range(3):
+    ops.corr_fwd(th, ph, bl, 1e-10, h, w)
+MAXT = 16
+nwg = 41 * 12
+buf = torch.zeros(nwg * MAXT * 4, dtype=torch.int64, device=dev)
+lib.dvc_debug_corr_timeline(ctypes.c_void_p(buf.data_ptr()), MAXT)
+ops.corr_fwd(th, ph, bl, 1e-10, h, w)
+torch.cuda.synchronize()
+lib.dvc_debug_corr_timeline(None, 0)
+t = buf.view(nwg, MAXT, 4).cpu().double()
+valid = t[:, :, 3] > 0
+t0 = t[:, 0, 0]
+print("workgroups:", nwg, "tiles recorded per wg (min/max):", int(valid.sum(1).min()), int(valid.sum(1).max()))
+full = valid.sum(1) >= 14
+tt = t[full][:, :14]
+per_tile = (tt[:, 1:, 0] - tt[:, :-1, 0]).mean().item()
+chain = (tt[:, :, 1] - tt[:, :, 0]).mean().item()
+fin = (tt[:, :, 2] - tt[:, :, 1]).mean().item()
+bar = (tt[:, :, 3] - tt[:, :, 2]).mean().item()
+print(f"ticks per tile {per_tile:.1f}: chain(+issue) {chain:.1f}  finish_tile {fin:.1f}  commit+barrier {bar:.1f}")
+start_spread = (t0.max() - t0.min()).item()
+end = t[full][:, 13, 3]
+print(f"first-tile start spread {start_spread:.0f} ticks; end spread of 14-tile wgs {(end.max()-end.min()).item():.0f}; "
+      f"total span {(t[valid][:, 3].max() - t0.min()).item():.0f} ticks")
+for k in range(14):
+    print(k, f"chain {(tt[:, k, 1]-tt[:, k, 0]).mean().item():.1f} fin {(tt[:, k, 2]-tt[:, k, 1]).mean().item():.1f} bar {(tt[:, k, 3]-tt[:, k, 2]).mean().item():.1f}")
