@@ -117,6 +117,12 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     const float* ph = a.phi + (long)b * CORR_C * P;
     const float* blb = a.blab + (long)b * 3 * P;
 
+    long long* dbgh = nullptr;  // debug header slot: [entry, loop start, loop end, exit]
+    if (a.dbg && tid == 0) {
+        dbgh = a.dbg + (((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * a.dbg_tiles +
+                        (a.dbg_tiles - 1)) * 4;
+        dbgh[0] = __builtin_amdgcn_s_memtime();
+    }
     // query fragment: B[k = 2s+hi][j = l31] for s = 0..127
     float qreg[CORR_C / 2];
 #pragma unroll
@@ -223,12 +229,13 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         commit(0, 0);
     }
     __syncthreads();  // (drains the LDS-DMA of the first tile)
+    if (dbgh) dbgh[1] = __builtin_amdgcn_s_memtime();
     long long* dbgp = nullptr;
     if (a.dbg && tid == 0)
         dbgp = a.dbg + ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * a.dbg_tiles * 4;
     for (int t = t0; t < t1; ++t) {
         const int cur = (t - t0) & 1;
-        if (dbgp && t - t0 < a.dbg_tiles) dbgp[(t - t0) * 4 + 0] = __builtin_amdgcn_s_memtime();
+        if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 0] = __builtin_amdgcn_s_memtime();
         issue(min(t + 1, t1 - 1), cur ^ 1);  // (the last iteration re-stages its own tile: harmless)
 
         // S^T tile of THIS key tile: 128 dependent MFMAs (K = 256) in 16 segments of 8.  The softmax of
@@ -257,14 +264,15 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
             // that neither can be hoisted / sunk out of its segment by earlier passes
             asm volatile("" : "+v"(acc), "+v"(l), "+v"(y0), "+v"(y1), "+v"(y2));
         }
-        if (dbgp && t - t0 < a.dbg_tiles) dbgp[(t - t0) * 4 + 1] = __builtin_amdgcn_s_memtime();
+        if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 1] = __builtin_amdgcn_s_memtime();
         finish_tile(acc, t * CORR_KT);
-        if (dbgp && t - t0 < a.dbg_tiles) dbgp[(t - t0) * 4 + 2] = __builtin_amdgcn_s_memtime();
+        if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 2] = __builtin_amdgcn_s_memtime();
         blp = bl + ((t - t0) % 3) * 256;
         commit(cur ^ 1, (t + 1 - t0) % 3);
         __syncthreads();  // next tile landed (DMA drained / stores visible); this tile's reads done
-        if (dbgp && t - t0 < a.dbg_tiles) dbgp[(t - t0) * 4 + 3] = __builtin_amdgcn_s_memtime();
+        if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 3] = __builtin_amdgcn_s_memtime();
     }
+    if (dbgh) dbgh[2] = __builtin_amdgcn_s_memtime();
     // drain: softmax of the last tile
     rescale();
 #pragma unroll
@@ -281,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         pp[5L * P] = fmax;
         pp[6L * P] = __int_as_float(amax);
     }
+    if (dbgh) dbgh[3] = __builtin_amdgcn_s_memtime();
 }
 
 // merge the 2*nsplit partial states of each query; write small + x4-upsampled outputs.

@@ -30,6 +30,18 @@ torch.cuda.synchronize()
 lib.dvc_debug_corr_timeline(None, 0)
 t = buf.view(nwg, MAXT, 4).cpu().double()
 valid = t[:, :, 3] > 0
+hdr = t[:, MAXT - 1, :]          # entry, loop start, loop end, exit
+t = t[:, :MAXT - 1, :]
+valid = t[:, :, 3] > 0
+base = hdr[:, 0].min()
+print("kernel entry  : min 0, median %.0f, max %.0f" % ((hdr[:, 0].median() - base).item(), (hdr[:, 0].max() - base).item()))
+print("prologue      : mean %.0f  (min %.0f max %.0f)" % ((hdr[:, 1] - hdr[:, 0]).mean().item(), (hdr[:, 1] - hdr[:, 0]).min().item(), (hdr[:, 1] - hdr[:, 0]).max().item()))
+print("tile loop     : mean %.0f  (min %.0f max %.0f)" % ((hdr[:, 2] - hdr[:, 1]).mean().item(), (hdr[:, 2] - hdr[:, 1]).min().item(), (hdr[:, 2] - hdr[:, 1]).max().item()))
+print("epilogue      : mean %.0f" % (hdr[:, 3] - hdr[:, 2]).mean().item())
+print("exit          : median %.0f, max %.0f  (= kernel span in ticks)" % ((hdr[:, 3].median() - base).item(), (hdr[:, 3].max() - base).item()))
+import collections
+order = torch.argsort(hdr[:, 0])
+print("entry time of wg #0,#128,#255,#256,#300,#400,#491 in dispatch order:", [(hdr[order[i], 0] - base).item() for i in (0, 128, 255, 256, 300, 400, 491)])
 t0 = t[:, 0, 0]
 print("workgroups:", nwg, "tiles recorded per wg (min/max):", int(valid.sum(1).min()), int(valid.sum(1).max()))
 full = valid.sum(1) >= 14
@@ -39,9 +51,5 @@ chain = (tt[:, :, 1] - tt[:, :, 0]).mean().item()
 fin = (tt[:, :, 2] - tt[:, :, 1]).mean().item()
 bar = (tt[:, :, 3] - tt[:, :, 2]).mean().item()
 print(f"ticks per tile {per_tile:.1f}: chain(+issue) {chain:.1f}  finish_tile {fin:.1f}  commit+barrier {bar:.1f}")
-start_spread = (t0.max() - t0.min()).item()
-end = t[full][:, 13, 3]
-print(f"first-tile start spread {start_spread:.0f} ticks; end spread of 14-tile wgs {(end.max()-end.min()).item():.0f}; "
-      f"total span {(t[valid][:, 3].max() - t0.min()).item():.0f} ticks")
 for k in range(14):
     print(k, f"chain {(tt[:, k, 1]-tt[:, k, 0]).mean().item():.1f} fin {(tt[:, k, 2]-tt[:, k, 1]).mean().item():.1f} bar {(tt[:, k, 3]-tt[:, k, 2]).mean().item():.1f}")
