@@ -109,14 +109,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     n_gpus = world
     if args.gpus != world:
@@ -146,18 +147,18 @@ def main():
     for i in range(Wm):
         last = step(i, last)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(Wm, Wm + K):
         last = step(i, last)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -218,7 +219,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

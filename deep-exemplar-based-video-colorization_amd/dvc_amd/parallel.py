@@ -37,7 +37,7 @@ def broadcast_exemplar(cc, IB_lab, shape, device, src=0):
     `cc` needs: .cache_exemplar, .set_exemplar(IB_lab), .IB_lab, .features_B, .ex_cache,
     and .exemplar_cache_shapes(shape) when cache_exemplar is on."""
     world, rank = _world()
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         cc.set_exemplar(IB_lab)
         return
     IB = IB_lab.contiguous() if rank == src else torch.empty(shape, device=device, dtype=torch.float32)
