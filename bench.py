@@ -118,7 +118,19 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if use_dist:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL prints a version banner on STDOUT at communicator creation; keep stdout for the ONE JSON
+        # line by pointing fd 1 at stderr while the communicator is created (first collective).
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     n_gpus = world
     if args.gpus != world:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}")
