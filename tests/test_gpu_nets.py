@@ -335,6 +335,59 @@ def test_drop_in_signature_and_loud_cpu_failure(nets):
         nets[2](torch.zeros(1, 7, 16, 16))      # CPU tensor must not silently fall back
 
 
+def test_config4_432x768_end_to_end(nets, weights):
+    """BASELINE configs[3]: 432x768 frames, N = 20736 correlation positions (the oracle's N x N path would
+    need ~7 GB per temporary).  VGG is compared with the fp64 oracle; the correlation is checked for
+    self-consistency against an fp64 evaluation of the theta/phi it consumed (argmax, similarity, exact
+    one-hot gather); the whole frame is checked for determinism and finiteness."""
+    from dvc_amd import ops, synth
+    from dvc_amd.frame import VGG_OUT, ClipColorizer
+    from oracle import dvc_oracle as O
+    from utils.util import feature_normalize, gray2rgb_batch
+    vgg, warp, col = nets
+    H, W, T = 432, 768, 1e-10
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
+    fr = synth.synth_lab(synth.FRAME_SEED0, H, W)
+    # VGG stage parity (fp64 truth)
+    x = O.gray2rgb_batch(fr[:, 0:1])
+    with torch.no_grad():
+        ref = O.vgg19_forward(O.to_dtype(weights[0], torch.float64), x.double(), ["r12", "r32", "r52"])
+    got = vgg(x.cuda(), ["r12", "r32", "r52"])
+    for k, g, r in zip(("r12", "r32", "r52"), got, ref):
+        assert rel(g, r) < 1e-4, k
+    # correlation self-consistency on the real features
+    fB = vgg(ops.lab2rgb(IB.cuda(), l_offset=50.0), VGG_OUT)
+    fA = vgg(gray2rgb_batch(fr.cuda()[:, 0:1]), VGG_OUT)
+    y, sim, tp = warp(IB.cuda(), *[feature_normalize(t) for t in fA[1:]], *[feature_normalize(t) for t in fB[1:]],
+                      temperature=T, return_taps=True)
+    assert y.shape == (1, 3, H, W) and sim.shape == (1, 1, H, W)
+    th, ph = tp["theta"][0].double(), tp["phi"][0].double()
+    P = th.shape[1]
+    assert P == 108 * 192
+    best_v = torch.empty(P, dtype=torch.float64, device="cuda")
+    best_i = torch.empty(P, dtype=torch.long, device="cuda")
+    gap = torch.empty(P, dtype=torch.float64, device="cuda")
+    for s0 in range(0, P, 4096):                        # chunked fp64 affinity rows (test-only torch ops)
+        f = th[:, s0:s0 + 4096].t() @ ph
+        t2 = torch.topk(f, 2, dim=-1)
+        best_v[s0:s0 + 4096], best_i[s0:s0 + 4096] = t2[0][:, 0], t2[1][:, 0]
+        gap[s0:s0 + 4096] = t2[0][:, 0] - t2[0][:, 1]
+    amax = tp["argmax"][0].long()
+    dis = amax != best_i
+    sim_err = (tp["sim_small"].view(-1).double() - best_v).abs().max().item()
+    blab = ops.avgpool4x4(IB.cuda()).view(3, -1)
+    colour_bad = ((tp["y_small"][0].view(3, -1) - blab[:, amax]).abs().max(0)[0] > 1e-3)
+    report(f"config4 432x768: argmax!=fp64 on {int(dis.sum())}/{P} rows (max gap {gap[dis].max().item() if dis.any() else 0:.2e}); "
+           f"colour!=blab[argmax] on {int(colour_bad.sum())}; sim_err={sim_err:.2e}")
+    assert sim_err < 2e-6 and (gap[dis] < 1e-5).all() and (gap[colour_bad] < 1e-5).all()
+    # whole frame: deterministic and finite
+    cc = ClipColorizer(vgg, warp, col, temperature=T)
+    cc.set_exemplar(IB.cuda())
+    a1, _ = cc.frame(fr.cuda(), torch.zeros_like(fr).cuda())
+    a2, _ = cc.frame(fr.cuda(), torch.zeros_like(fr).cuda())
+    assert a1.shape == (1, 2, H, W) and torch.isfinite(a1).all() and torch.equal(a1, a2)
+
+
 def test_full_res_432x768_properties(nets):
     """BASELINE configs[3]: N = 20736 positions — size-independent properties only (the oracle would
     need 7 GB of N x N temporaries): one-hot gather identity, sim in [-1,1], determinism."""
