@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="use the static tile cost model instead of first-use timing")
+    ap.add_argument("--corr", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16 = BASELINE configs[4]: bf16 MFMA candidate filter + exact fp32 re-scoring")
     ap.add_argument("--no-exemplar-cache", action="store_true",
                     help="recompute the exemplar side of WarpNet every frame, as the reference does")
     args = ap.parse_args()
@@ -141,6 +143,7 @@ def main():
 
     ops.set_autotune(not args.no_autotune)   # like the reference's cudnn.benchmark = True (test.py:140)
     nets, sd = build_nets(device)
+    nets[1].corr_precision = args.corr
     cc = ClipColorizer(*nets, temperature=1e-10, cache_exemplar=not args.no_exemplar_cache)
     # exemplar: prepared on rank 0, shared once with every rank (RCCL broadcast over xGMI)
     IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).to(device)
@@ -223,6 +226,8 @@ def main():
                                    "VGG19 + WarpNet/fused correlation + ColorVidNet forward, fp32, clip "
                                    "recurrence as test.py:68-96",
                        "H": H, "W": W, "temperature": 1e-10, "weights": "synthetic seed 0",
+                       "correlation": "fp32 MFMA" if args.corr == "fp32" else
+                       "bf16 MFMA candidate filter + exact fp32 re-scoring (configs[4])",
                        "exemplar_side": "recomputed per frame" if args.no_exemplar_cache else "cached per clip",
                        "conv_tile_choice": "static cost model" if args.no_autotune else
                        "autotuned on first use during warm-up (cf. cudnn.benchmark=True, test.py:140)",

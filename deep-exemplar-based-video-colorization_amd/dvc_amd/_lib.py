@@ -50,6 +50,10 @@ SIGNATURES = {
     "dvc_corr_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "dvc_corr_fwd": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_float, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,
                                     _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_size_t, _VP]),
+    "dvc_corr_prepare_bf16": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP, _VP]),
+    "dvc_corr_bf16_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
+    "dvc_corr_fwd_bf16": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,
+                                         _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_size_t, _VP]),
 }
 
 _lib = None

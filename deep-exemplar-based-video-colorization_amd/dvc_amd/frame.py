@@ -76,13 +76,15 @@ class ClipColorizer:
         self.ex_cache = None
         if self.cache_exemplar:
             nB = [feature_normalize(t) for t in self.features_B[1:]]
-            self.ex_cache = self.warp.exemplar_side(IB_lab, *nB)
+            self.ex_cache = self.warp.exemplar_side(IB_lab, *nB, bf16=self.warp._use_bf16(self.temperature, 1))
         return self.features_B
 
     def exemplar_cache_shapes(self, lab_shape):
         """Shapes of (phi, pooled Lab) for an exemplar of `lab_shape` (used by parallel.broadcast_exemplar)."""
         n, _, H, W = lab_shape
         h, w = int(H / 4), int(W / 4)
+        if self.warp._use_bf16(self.temperature, 1):
+            raise NotImplementedError("broadcasting a bf16 exemplar cache: let every rank call set_exemplar")
         return [(n, 256, h * w), (n, 3, h, w)]
 
     def frame(self, IA_lab, IA_last_lab):

@@ -135,8 +135,14 @@ class WarpNet(nn.Module):
         self.theta = nn.Conv2d(self.in_channels, self.inter_channels, kernel_size=1, stride=1, padding=0)
         self.phi = nn.Conv2d(self.in_channels, self.inter_channels, kernel_size=1, stride=1, padding=0)
         self._cache = _PackCache()
+        # "fp32": exact-fp32 MFMA affinities.  "bf16": bf16 MFMA candidate filter + exact fp32 re-scoring
+        # (BASELINE configs[4]); exact for temperature <= 1e-4, otherwise the fp32 kernel is used.
+        self.corr_precision = "fp32"
 
     # -- helpers
+    def _use_bf16(self, temperature, WTA_scale_weight):
+        return self.corr_precision == "bf16" and float(temperature) <= 1e-4 and WTA_scale_weight == 1
+
     def _pk(self, key, conv):
         return self._cache.get(key, conv.weight, ops.pack_conv_weight)
 
@@ -195,16 +201,19 @@ class WarpNet(nn.Module):
             x = ops.affine_act(t, sc, sh, residual=x, slope_t=a)
         return x
 
-    def project(self, which, feats):
-        """theta / phi: 1x1 conv, centre over positions, L2-normalise over channels -> [N,256,P]."""
+    def project(self, which, feats, bf16=False):
+        """theta / phi: 1x1 conv, centre over positions, L2-normalise over channels -> [N,256,P]
+        (bf16=True: the ([N,P,256] fp32, [N,P,256] bf16) pair the bf16 correlation consumes)."""
         conv = getattr(self, which)
         t = ops.conv2d(feats, self._pk(which, conv), conv.bias.detach(), ksize=1, pad=0)
-        return ops.corr_prepare(t)
+        return ops.corr_prepare_bf16(t) if bf16 else ops.corr_prepare(t)
 
-    def exemplar_side(self, B_lab_map, B2, B3, B4, B5):
+    def exemplar_side(self, B_lab_map, B2, B3, B4, B5, bf16=None):
         """Everything that depends only on the exemplar (recomputed per frame by the reference,
         NonlocalNet.py:452-465,473-476,491-493; cacheable per clip)."""
-        phi = self.project("phi", self.features(B2, B3, B4, B5))
+        if bf16 is None:
+            bf16 = self.corr_precision == "bf16"
+        phi = self.project("phi", self.features(B2, B3, B4, B5), bf16=bf16)
         blab = ops.avgpool4x4(B_lab_map)
         return phi, blab
 
@@ -223,14 +232,21 @@ class WarpNet(nn.Module):
         if (A_features.shape[2], A_features.shape[3]) != (fh, fw):
             raise RuntimeError(f"shape '[{B_lab_map.shape[0]}, 1, {fh}, {fw}]' is invalid for feature map "
                                f"of size {tuple(A_features.shape[2:])}")
-        theta = self.project("theta", A_features)
+        bf16 = self._use_bf16(temperature, WTA_scale_weight)
         if exemplar_cache is not None:
             phi, blab = exemplar_cache
+            if isinstance(phi, tuple) != bf16:
+                raise RuntimeError("exemplar cache was built for a different corr_precision / temperature regime")
         else:
-            phi, blab = self.exemplar_side(B_lab_map, B2, B3, B4, B5)
-        res = ops.corr_fwd(theta, phi, blab.view(blab.shape[0], 3, -1), float(temperature), fh, fw,
-                           wta_scale=float(WTA_scale_weight), want_small=return_taps,
-                           want_argmax=return_taps)
+            phi, blab = self.exemplar_side(B_lab_map, B2, B3, B4, B5, bf16=bf16)
+        theta = self.project("theta", A_features, bf16=bf16)
+        if bf16:
+            res = ops.corr_fwd_bf16(theta, phi, blab.view(blab.shape[0], 3, -1), float(temperature), fh, fw,
+                                    want_small=return_taps, want_argmax=return_taps)
+        else:
+            res = ops.corr_fwd(theta, phi, blab.view(blab.shape[0], 3, -1), float(temperature), fh, fw,
+                               wta_scale=float(WTA_scale_weight), want_small=return_taps,
+                               want_argmax=return_taps)
         if return_taps:
             return res["y_up"], res["sim_up"], dict(theta=theta, phi=phi, y_small=res["y_small"],
                                                     sim_small=res["sim_small"], argmax=res["argmax"],

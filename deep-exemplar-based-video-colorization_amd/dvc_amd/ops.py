@@ -311,3 +311,45 @@ def corr_fwd(theta, phi, blab, temperature, h, w, wta_scale=1.0, want_small=Fals
     _lib.check(rc, "dvc_corr_fwd")
     out.update(y_up=y_up, sim_up=sim_up, y_small=y_small, sim_small=sim_small, argmax=amax)
     return out
+
+
+def corr_prepare_bf16(t_raw, eps=EPS64):
+    """t_raw [B,C,h,w] or [B,C,P] -> (fp32 [B,P,C], bf16 [B,P,C] stored as int16) centred + normalised."""
+    lib = _lib.load()
+    _need(t_raw, "t_raw")
+    B, C = t_raw.shape[0], t_raw.shape[1]
+    P = t_raw[0, 0].numel()
+    f32 = torch.empty((B, P, C), device=t_raw.device, dtype=torch.float32)
+    b16 = torch.empty((B, P, C), device=t_raw.device, dtype=torch.int16)
+    mean = torch.empty(B * C, device=t_raw.device, dtype=torch.float32)
+    _lib.check(lib.dvc_corr_prepare_bf16(_p(t_raw), B, C, P, float(eps), _p(mean), _p(f32),
+                                         ctypes.c_void_p(b16.data_ptr()), _stream()), "dvc_corr_prepare_bf16")
+    return f32, b16
+
+
+def corr_fwd_bf16(theta, phi, blab, temperature, h, w, want_small=False, want_argmax=False, want_up=True):
+    """bf16 candidate filter + exact fp32 re-scoring.  theta/phi: (fp32 [B,P,C], bf16 [B,P,C]) pairs from
+    corr_prepare_bf16; blab [B,3,P].  Same outputs as corr_fwd.  Requires temperature <= 1e-4."""
+    lib = _lib.load()
+    (tf, tb), (pf, pb) = theta, phi
+    for t, nm in ((tf, "theta"), (pf, "phi"), (blab, "blab")):
+        _need(t, nm)
+    B, P, C = tf.shape
+    assert P == h * w
+    dev = tf.device
+    y_up = sim_up = y_small = sim_small = amax = None
+    if want_up:
+        y_up = torch.empty((B, 3, 4 * h, 4 * w), device=dev, dtype=torch.float32)
+        sim_up = torch.empty((B, 1, 4 * h, 4 * w), device=dev, dtype=torch.float32)
+    if want_small:
+        y_small = torch.empty((B, 3, h, w), device=dev, dtype=torch.float32)
+        sim_small = torch.empty((B, 1, h, w), device=dev, dtype=torch.float32)
+    if want_argmax:
+        amax = torch.empty((B, P), device=dev, dtype=torch.int32)
+    ws = _workspace(dev, lib.dvc_corr_bf16_workspace_bytes(B, P), "corr_bf16")
+    rc = lib.dvc_corr_fwd_bf16(ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(pb.data_ptr()), _p(tf), _p(pf),
+                               _p(blab), float(temperature), B, C, h, w, _p(y_small), _p(sim_small), _p(y_up),
+                               _p(sim_up), None if amax is None else ctypes.c_void_p(amax.data_ptr()),
+                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    _lib.check(rc, "dvc_corr_fwd_bf16")
+    return dict(y_up=y_up, sim_up=sim_up, y_small=y_small, sim_small=sim_small, argmax=amax)

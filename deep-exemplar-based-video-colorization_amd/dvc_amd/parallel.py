@@ -42,8 +42,8 @@ def broadcast_exemplar(cc, IB_lab, shape, device, src=0):
         return
     IB = IB_lab.contiguous() if rank == src else torch.empty(shape, device=device, dtype=torch.float32)
     dist.broadcast(IB, src)
-    if not cc.cache_exemplar:
-        cc.set_exemplar(IB)          # every rank needs the exemplar's VGG features
+    if not cc.cache_exemplar or getattr(getattr(cc, "warp", None), "corr_precision", "fp32") != "fp32":
+        cc.set_exemplar(IB)          # every rank prepares the exemplar side itself
         return
     if rank == src:
         cc.set_exemplar(IB)

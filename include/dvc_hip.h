@@ -171,6 +171,22 @@ int dvc_corr_fwd(const float* theta, const float* phi, const float* blab, float 
                  float* sim_small, float* y_up, float* sim_up, int32_t* argmax, void* workspace,
                  size_t workspace_bytes, dvcStream stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * bf16 mixed-precision correlation (BASELINE.json configs[4]).  Same reference lines as dvc_corr_fwd
+ * (models/NonlocalNet.py:469-500); bf16 MFMA affinities are used as a candidate filter and every key
+ * within 2*2^-8 of the bf16 row maximum is re-scored in exact fp32, which provably contains the fp32
+ * argmax (unit-norm columns => |f_bf16 - f| <= 2^-8).  Exact for temperature <= 1e-4 (test.py:94 uses
+ * 1e-10); larger temperatures are rejected (use dvc_corr_fwd).
+ */
+/* t_raw[B][C][P] -> centred + normalised copies in [B][P][C] layout: fp32 and bf16 (round-to-nearest-even). */
+int dvc_corr_prepare_bf16(const float* t_raw, int32_t B, int32_t C, int32_t P, float eps,
+                          float* mean_scratch, float* t_f32_pc, void* t_bf16_pc, dvcStream stream);
+size_t dvc_corr_bf16_workspace_bytes(int32_t B, int32_t P);
+int dvc_corr_fwd_bf16(const void* theta_bf16_pc, const void* phi_bf16_pc, const float* theta_f32_pc,
+                      const float* phi_f32_pc, const float* blab, float temperature, int32_t B, int32_t C,
+                      int32_t h, int32_t w, float* y_small, float* sim_small, float* y_up, float* sim_up,
+                      int32_t* argmax, void* workspace, size_t workspace_bytes, dvcStream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -335,6 +335,45 @@ def test_drop_in_signature_and_loud_cpu_failure(nets):
         nets[2](torch.zeros(1, 7, 16, 16))      # CPU tensor must not silently fall back
 
 
+def test_config5_bf16_correlation_path(nets, weights):
+    """BASELINE configs[4] end to end at 216x384: WarpNet with corr_precision='bf16' (bf16 MFMA candidate
+    filter + fp32 re-scoring) against the fp32 path.  Restated tolerance: identical exemplar pixel on
+    every row whose fp32 top-1/top-2 gap exceeds 1e-5, similarity map within 2e-6, hence identical warped
+    colours there; `ab` is then compared like any two fp32 runs (mean < 1e-3).  A soft temperature (0.01)
+    silently uses the fp32 kernel (bit-identical)."""
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    vgg, warp, col = nets
+    H, W = 216, 384
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).cuda()
+    fr = synth.synth_lab(synth.FRAME_SEED0 + 1, H, W).cuda()
+    last = torch.zeros_like(fr)
+    outs = {}
+    try:
+        for prec in ("fp32", "bf16"):
+            warp.corr_precision = prec
+            cc = ClipColorizer(vgg, warp, col, temperature=1e-10)
+            cc.set_exemplar(IB)
+            outs[prec] = cc.frame(fr, last)
+        warp.corr_precision = "bf16"
+        cs = ClipColorizer(vgg, warp, col, temperature=0.01)
+        cs.set_exemplar(IB)
+        soft_b = cs.frame(fr, last)
+        warp.corr_precision = "fp32"
+        cs = ClipColorizer(vgg, warp, col, temperature=0.01)
+        cs.set_exemplar(IB)
+        soft_f = cs.frame(fr, last)
+    finally:
+        warp.corr_precision = "fp32"
+    wl = (outs["bf16"][1] - outs["fp32"][1]).abs()[0, :, ::4, ::4].max(0)[0]
+    d = (outs["bf16"][0] - outs["fp32"][0]).abs()
+    report(f"config5 bf16 corr: warped rows differing {int((wl > 1e-3).sum())}/5184, ab diff max={d.max():.2e} mean={d.mean():.2e}")
+    assert int((wl > 1e-3).sum()) <= 2          # only exact/near ties may differ
+    if int((wl > 1e-3).sum()) == 0:
+        assert d.mean().item() < 1e-3
+    assert torch.equal(soft_b[0], soft_f[0]) and torch.equal(soft_b[1], soft_f[1])
+
+
 def test_config4_432x768_end_to_end(nets, weights):
     """BASELINE configs[3]: 432x768 frames, N = 20736 correlation positions (the oracle's N x N path would
     need ~7 GB per temporary).  VGG is compared with the fp64 oracle; the correlation is checked for

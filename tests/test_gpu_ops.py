@@ -279,6 +279,61 @@ def test_corr_fwd_vs_oracle(ops, h, w, B, T):
         assert torch.equal(out["y_small"].view(B, 3, P)[rows], gathered[rows])
 
 
+@pytest.mark.parametrize("h,w,B,mode", [(10, 16, 1, "random"), (12, 20, 2, "random"), (54, 96, 1, "random"),
+                                       (54, 96, 1, "clustered"), (27, 48, 1, "overflow")])
+def test_corr_bf16_candidate_filter_is_exact(ops, h, w, B, mode):
+    """BASELINE configs[4]: bf16 MFMA candidate filter + exact fp32 re-scoring must reproduce the fp32
+    path's argmax / similarity / one-hot colour at the inference temperature — including when many keys
+    are near-ties within the bf16 error ('clustered': exemplar features drawn from 40 prototypes plus
+    1e-3 noise) and when a candidate list overflows ('overflow': 200 almost identical keys).
+    Tolerance: similarity 2e-6 (both are fp32 dot products, different summation order); argmax equal
+    wherever the fp32 top-1/top-2 gap exceeds 1e-5; colour exact on those rows."""
+    g = torch.Generator().manual_seed(h * 7 + w + len(mode))
+    P = h * w
+    raw_t = torch.randn(B, 256, P, generator=g)
+    if mode == "random":
+        raw_p = torch.randn(B, 256, P, generator=g)
+    elif mode == "clustered":
+        proto = torch.randn(B, 256, 40, generator=g)
+        idx = torch.randint(0, 40, (P,), generator=g)
+        raw_p = proto[:, :, idx] + 1e-3 * torch.randn(B, 256, P, generator=g)
+        raw_t = proto[:, :, torch.randint(0, 40, (P,), generator=g)] + 0.3 * torch.randn(B, 256, P, generator=g)
+    else:
+        raw_p = torch.randn(B, 256, P, generator=g)
+        raw_p[:, :, 100:300] = raw_p[:, :, 100:101] + 1e-5 * torch.randn(B, 256, 200, generator=g)
+        raw_t[:, :, :64] = raw_p[:, :, 100:101] + 0.05 * torch.randn(B, 256, 64, generator=g)
+    lab_map = torch.randn(B, 3, 4 * h, 4 * w, generator=g) * 30
+    blab = ops.avgpool4x4(lab_map.cuda()).view(B, 3, P)
+    T = 1e-10
+    th32, ph32 = ops.corr_prepare(raw_t.cuda()), ops.corr_prepare(raw_p.cuda())
+    ref = ops.corr_fwd(th32, ph32, blab, T, h, w, want_small=True, want_argmax=True)
+    thb, phb = ops.corr_prepare_bf16(raw_t.cuda()), ops.corr_prepare_bf16(raw_p.cuda())
+    # the [P][C] fp32 copy is the transposed fp32 theta
+    assert (thb[0].transpose(1, 2) - th32).abs().max().item() < 1e-7
+    out = ops.corr_fwd_bf16(thb, phb, blab, T, h, w, want_small=True, want_argmax=True)
+    torch.cuda.synchronize()
+    f = th32[0].double().t() @ ph32[0].double() if B == 1 else None
+    sim_err = (out["sim_small"] - ref["sim_small"]).abs().max().item()
+    agree = out["argmax"] == ref["argmax"]
+    if f is not None:
+        top2 = torch.topk(f, 2, dim=-1)[0]
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-5
+        agree_safe = agree[0][safe].float().mean().item()
+        col_err = (out["y_small"].view(B, 3, P) - ref["y_small"].view(B, 3, P)).abs().max(1)[0][0][safe].max().item()
+    else:
+        agree_safe, col_err = agree.float().mean().item(), 0.0
+    report(f"corr_bf16 {mode} h={h} w={w} B={B}: sim_err={sim_err:.2e} argmax_agree_all={agree.float().mean():.5f} "
+           f"agree_safe={agree_safe:.5f} colour_err_safe={col_err:.2e}")
+    assert sim_err < 2e-6
+    assert agree_safe == 1.0
+    assert col_err == 0.0
+    assert torch.equal(out["y_up"], F.interpolate(out["y_small"], scale_factor=4, mode="nearest"))
+    again = ops.corr_fwd_bf16(thb, phb, blab, T, h, w, want_small=True, want_argmax=True)
+    assert torch.equal(again["y_small"], out["y_small"]) and torch.equal(again["argmax"], out["argmax"])
+    with pytest.raises(RuntimeError, match="temperature"):
+        ops.corr_fwd_bf16(thb, phb, blab, 0.01, h, w)
+
+
 def test_corr_fwd_wta(ops):
     from oracle import dvc_oracle as O
     g = torch.Generator().manual_seed(77)
