@@ -51,6 +51,38 @@ _tuned = {}
 def set_autotune(flag=True):
     global _autotune
     _autotune = bool(flag)
+    if _autotune:
+        _load_tuned()
+
+
+# optional persistence (DVC_AUTOTUNE_CACHE=<file.json>): tune once, reuse in later processes — e.g. so
+# that a profiled run contains production launches only
+_cache_path = _os.environ.get("DVC_AUTOTUNE_CACHE")
+_cache_loaded = False
+
+
+def _load_tuned():
+    global _cache_loaded
+    if _cache_loaded or not _cache_path:
+        return
+    _cache_loaded = True
+    try:
+        import json
+        with open(_cache_path) as f:
+            for k, v in json.load(f).items():
+                _tuned[tuple(json.loads(k))] = tuple(v)
+    except (OSError, ValueError):
+        pass
+
+
+def _save_tuned():
+    if not _cache_path:
+        return
+    import json
+    tmp = _cache_path + ".tmp%d" % _os.getpid()
+    with open(tmp, "w") as f:
+        json.dump({json.dumps(list(k)): list(v) for k, v in _tuned.items()}, f)
+    _os.replace(tmp, _cache_path)
 
 
 def autotune_table():
@@ -99,6 +131,7 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
         if best is None:
             best = _tune_conv(lib, d, (x, w_packed, bias, in_scale, in_shift, in_slope_t, act_slope_t, residual, out))
             _tuned[key] = best
+            _save_tuned()
         d.cfg, d.split_k = best
     if conv_record is not None:
         conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=ksize, stride=stride, dil=dil, pad=pad,
@@ -110,6 +143,10 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     _lib.check(rc, "dvc_conv2d")
     return out
+
+
+if _autotune:
+    _load_tuned()  # env-enabled autotune: pick up a persisted table
 
 
 def _tune_conv(lib, d, tensors):
