@@ -91,10 +91,18 @@ struct CorrArgs {
     const float* fmax_in;  // WTA pass only: row maxima from the first pass
     float* part;           // [B][nslot][CORR_NF][P]
     float T, invT, wta_scale;
-    int P, ntiles, tiles_per_split, nslot;
+    int P, ntiles, nqb, nslot;   // nqb: query blocks per image; nslot: partial-state slots per query (max)
+    long U;                      // work units = B * nqb * ntiles, dealt out evenly to gridDim.x workgroups
     long long* dbg;        // debug timeline (NULL in production): [workgroup][tile][4] s_memtime stamps of wave 0
     int dbg_tiles;
 };
+
+// stream-K style decomposition: unit u = (image * nqb + query block) * ntiles + key tile; workgroup w owns the
+// contiguous range [w*U/G, (w+1)*U/G) — every workgroup gets the same number of key tiles (+-1), whatever
+// P is.  A range spans at most two query blocks (ranges are shorter than ntiles); each (workgroup, query
+// block) pair produces one partial state, stored in slot (w - first workgroup of that query block).
+__host__ __device__ __forceinline__ long corr_unit_start(long w, long U, long G) { return w * U / G; }
+__host__ __device__ __forceinline__ long corr_unit_owner(long u, long U, long G) { return ((u + 1) * G - 1) / U; }
 
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
@@ -109,20 +117,27 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, split = blockIdx.y;
     const int P = a.P;
-    const int query = blockIdx.x * CORR_QB + wave * 32 + l31;
+    const long G = gridDim.x;
+    long u = corr_unit_start(blockIdx.x, a.U, G);
+    const long u_end = corr_unit_start(blockIdx.x + 1, a.U, G);
+    long long* dbgh = nullptr;  // debug header slot: [entry, loop start, loop end, exit] of the first segment
+    if (a.dbg && tid == 0) {
+        dbgh = a.dbg + ((long)blockIdx.x * a.dbg_tiles + (a.dbg_tiles - 1)) * 4;
+        dbgh[0] = __builtin_amdgcn_s_memtime();
+    }
+  while (u < u_end) {  // one iteration per (query block) segment of this workgroup's unit range: 1 or 2
+    const int qbg = (int)(u / a.ntiles);
+    const int t0 = (int)(u - (long)qbg * a.ntiles);
+    const int t1 = (int)min((long)a.ntiles, t0 + (u_end - u));
+    const int b = qbg / a.nqb, qb = qbg - b * a.nqb;
+    const int slot0 = (int)(blockIdx.x - corr_unit_owner((long)qbg * a.ntiles, a.U, G)) * 2;
+    const int query = qb * CORR_QB + wave * 32 + l31;
     const bool qvalid = query < P;
     const float* th = a.theta + (long)b * CORR_C * P;
     const float* ph = a.phi + (long)b * CORR_C * P;
     const float* blb = a.blab + (long)b * 3 * P;
 
-    long long* dbgh = nullptr;  // debug header slot: [entry, loop start, loop end, exit]
-    if (a.dbg && tid == 0) {
-        dbgh = a.dbg + (((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * a.dbg_tiles +
-                        (a.dbg_tiles - 1)) * 4;
-        dbgh[0] = __builtin_amdgcn_s_memtime();
-    }
     // query fragment: B[k = 2s+hi][j = l31] for s = 0..127
     float qreg[CORR_C / 2];
 #pragma unroll
@@ -132,9 +147,6 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     int amax = 0;
     float fq = 0.f;
     if (WTA) fq = qvalid ? a.fmax_in[(long)b * P + query] : 0.f;
-
-    const int t0 = split * a.tiles_per_split;
-    const int t1 = min(a.ntiles, t0 + a.tiles_per_split);
 
     // ---- key-tile staging into smem[buf][c][0..31] = phi[c][k0..k0+31]
     // VEC4 (P % 4 == 0): LDS-DMA, no VGPRs — a wave instruction moves 8 rows x 128 B (lane -> row
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     if (dbgh) dbgh[1] = __builtin_amdgcn_s_memtime();
     long long* dbgp = nullptr;
     if (a.dbg && tid == 0)
-        dbgp = a.dbg + ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * a.dbg_tiles * 4;
+        dbgp = a.dbg + (long)blockIdx.x * a.dbg_tiles * 4;
     for (int t = t0; t < t1; ++t) {
         const int cur = (t - t0) & 1;
         if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 0] = __builtin_amdgcn_s_memtime();
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
 
     // ---- write this lane's partial state: slot = split*2 + hi
     if (qvalid) {
-        float* pp = a.part + (((long)b * a.nslot + split * 2 + hi) * CORR_NF) * P + query;
+        float* pp = a.part + (((long)b * a.nslot + slot0 + hi) * CORR_NF) * P + query;
         pp[0] = m;
         pp[(long)P] = l;
         pp[2L * P] = y0;
@@ -289,13 +301,20 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         pp[5L * P] = fmax;
         pp[6L * P] = __int_as_float(amax);
     }
-    if (dbgh) dbgh[3] = __builtin_amdgcn_s_memtime();
+    if (dbgh) {
+        dbgh[3] = __builtin_amdgcn_s_memtime();
+        dbgh = nullptr;
+    }
+    u += t1 - t0;
+    __syncthreads();  // LDS buffers are reused by the next segment
+  }
 }
 
 // merge the 2*nsplit partial states of each query; write small + x4-upsampled outputs.
 // Workgroup = 64 queries x 4 slot groups: the slot loop is 4x shorter and 4x more loads are in flight
 // than with one thread per query (this kernel is pure L2 latency).
 __global__ __launch_bounds__(256) void corr_merge_kernel(const float* __restrict__ part, int nslot, int P,
+                                                         int nqb, int ntiles, long U, long G,
                                                          int h, int w, float* __restrict__ y_small,
                                                          float* __restrict__ sim_small,
                                                          float* __restrict__ y_up,
@@ -307,10 +326,13 @@ __global__ __launch_bounds__(256) void corr_merge_kernel(const float* __restrict
     const int b = blockIdx.y;
     const bool ok = q < P;
     const float* pb = part + (long)b * nslot * CORR_NF * P + (ok ? q : 0);
+    // the partial states of this query block were written by workgroups w_lo..w_hi (2 slots each)
+    const long qbg = (long)b * nqb + (blockIdx.x * 64) / CORR_QB;   // 64 | CORR_QB: one query block per workgroup
+    const int nused = (int)(corr_unit_owner((qbg + 1) * ntiles - 1, U, G) - corr_unit_owner(qbg * ntiles, U, G) + 1) * 2;
     // pass 1 (this group's slots): running max of m, best (fmax, argmax)
     float M = -INFINITY, F = -INFINITY;
     int A = 0x7fffffff;
-    for (int s = g; s < nslot; s += 4) {
+    for (int s = g; s < nused; s += 4) {
         const float* ps = pb + (long)s * CORR_NF * P;
         M = fmaxf(M, ps[0]);
         float f = ps[5L * P];
@@ -326,7 +348,7 @@ __global__ __launch_bounds__(256) void corr_merge_kernel(const float* __restrict
     M = fmaxf(fmaxf(sh[0][0][qx_], sh[1][0][qx_]), fmaxf(sh[2][0][qx_], sh[3][0][qx_]));
     // pass 2: rescaled sums of this group's slots
     float L = 0.f, Y0 = 0.f, Y1 = 0.f, Y2 = 0.f;
-    for (int s = g; s < nslot; s += 4) {
+    for (int s = g; s < nused; s += 4) {
         const float* ps = pb + (long)s * CORR_NF * P;
         float ms = ps[0];
         float sc = (ms == -INFINITY) ? 0.f : expf(ms - M);
@@ -377,21 +399,28 @@ __global__ __launch_bounds__(256) void corr_merge_kernel(const float* __restrict
     }
 }
 
-static void corr_split(int B, int P, int* ntiles, int* tps, int* nsplit) {
-    int qblocks = cdiv(P, CORR_QB);
-    *ntiles = cdiv(P, CORR_KT);
-    int want = 512 / (qblocks * B);  // 2 resident workgroups per CU x 256 CUs
-    if (want < 1) want = 1;
-    if (want > *ntiles) want = *ntiles;
-    *tps = cdiv(*ntiles, want);
-    *nsplit = cdiv(*ntiles, *tps);
+// decomposition parameters shared by the launch and the workspace query
+struct CorrPlan {
+    int ntiles, nqb, nslot;
+    long U, G;
+};
+static CorrPlan corr_plan(int B, int P) {
+    CorrPlan p;
+    p.ntiles = cdiv(P, CORR_KT);
+    p.nqb = cdiv(P, CORR_QB);
+    p.U = (long)B * p.nqb * p.ntiles;
+    p.G = p.U < 512 ? p.U : 512;  // 2 resident workgroups per CU x 256 CUs
+    // at most ceil(ntiles / floor(U/G)) + 1 workgroups touch one query block
+    long per = p.U / p.G;
+    if (per < 1) per = 1;
+    p.nslot = (int)((p.ntiles + per - 1) / per + 1) * 2;
+    return p;
 }
 
 extern "C" size_t dvc_corr_workspace_bytes(int32_t B, int32_t P) {
     if (B <= 0 || P <= 0) return 0;
-    int ntiles, tps, nsplit;
-    corr_split(B, P, &ntiles, &tps, &nsplit);
-    size_t part = (size_t)B * nsplit * 2 * CORR_NF * P * sizeof(float);
+    CorrPlan p = corr_plan(B, P);
+    size_t part = (size_t)B * p.nslot * CORR_NF * P * sizeof(float);
     size_t fmax = (size_t)B * P * sizeof(float);
     return part + fmax + 256;
 }
@@ -423,24 +452,24 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
     a.dbg = g_corr_dbg; a.dbg_tiles = g_corr_dbg_tiles;
     a.theta = theta; a.phi = phi; a.blab = blab;
     a.T = temperature; a.invT = 1.0f / temperature; a.wta_scale = wta_scale; a.P = P;
-    int nsplit;
-    corr_split(B, P, &a.ntiles, &a.tiles_per_split, &nsplit);
-    a.nslot = nsplit * 2;
+    const CorrPlan pl = corr_plan(B, P);
+    a.ntiles = pl.ntiles; a.nqb = pl.nqb; a.nslot = pl.nslot; a.U = pl.U;
     a.part = reinterpret_cast<float*>(workspace);
     float* fmax_buf = a.part + (size_t)B * a.nslot * CORR_NF * P;
     a.fmax_in = fmax_buf;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(cdiv(P, CORR_QB), nsplit, B);
+    dim3 grid((unsigned)pl.G);
     const bool vec4 = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(phi) & 15) == 0);
     dim3 mgrid(cdiv(P, 64), B);
+    static_assert(CORR_QB % 64 == 0, "merge kernel assumes one query block per 64-query workgroup");
     const bool wta = wta_scale != 1.0f;
     if (wta) {
         // pass 1: row maxima only (identical MFMA order => `f == rowmax` is exact in pass 2)
         if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((corr_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
         DVC_CHECK_LAUNCH("dvc_corr_fwd(pass1)");
-        hipLaunchKernelGGL(corr_merge_kernel, mgrid, dim3(256), 0, s, a.part, a.nslot, P, h, w,
-                           (float*)nullptr, fmax_buf, (float*)nullptr, (float*)nullptr, (int*)nullptr);
+        hipLaunchKernelGGL(corr_merge_kernel, mgrid, dim3(256), 0, s, a.part, a.nslot, P, pl.nqb, pl.ntiles, pl.U,
+                           pl.G, h, w, (float*)nullptr, fmax_buf, (float*)nullptr, (float*)nullptr, (int*)nullptr);
         DVC_CHECK_LAUNCH("dvc_corr_fwd(merge1)");
         if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((corr_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
@@ -449,8 +478,8 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
         else hipLaunchKernelGGL((corr_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
     }
     DVC_CHECK_LAUNCH("dvc_corr_fwd");
-    hipLaunchKernelGGL(corr_merge_kernel, mgrid, dim3(256), 0, s, a.part, a.nslot, P, h, w, y_small,
-                       sim_small, y_up, sim_up, argmax);
+    hipLaunchKernelGGL(corr_merge_kernel, mgrid, dim3(256), 0, s, a.part, a.nslot, P, pl.nqb, pl.ntiles, pl.U, pl.G,
+                       h, w, y_small, sim_small, y_up, sim_up, argmax);
     DVC_CHECK_LAUNCH("dvc_corr_fwd(merge)");
     return 0;
 }

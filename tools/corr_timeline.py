@@ -22,7 +22,7 @@ bl = torch.randn(1, 3, P, generator=g).to(dev)
 for _ in range(3):
     ops.corr_fwd(th, ph, bl, 1e-10, h, w)
 MAXT = 16
-nwg = 41 * 12
+nwg = 512
 buf = torch.zeros(nwg * MAXT * 4, dtype=torch.int64, device=dev)
 lib.dvc_debug_corr_timeline(ctypes.c_void_p(buf.data_ptr()), MAXT)
 ops.corr_fwd(th, ph, bl, 1e-10, h, w)
@@ -44,12 +44,13 @@ order = torch.argsort(hdr[:, 0])
 print("entry time of wg #0,#128,#255,#256,#300,#400,#491 in dispatch order:", [(hdr[order[i], 0] - base).item() for i in (0, 128, 255, 256, 300, 400, 491)])
 t0 = t[:, 0, 0]
 print("workgroups:", nwg, "tiles recorded per wg (min/max):", int(valid.sum(1).min()), int(valid.sum(1).max()))
-full = valid.sum(1) >= 14
-tt = t[full][:, :14]
+NT = int(valid.sum(1).max()) - 1
+full = valid.sum(1) >= NT
+tt = t[full][:, :NT]
 per_tile = (tt[:, 1:, 0] - tt[:, :-1, 0]).mean().item()
 chain = (tt[:, :, 1] - tt[:, :, 0]).mean().item()
 fin = (tt[:, :, 2] - tt[:, :, 1]).mean().item()
 bar = (tt[:, :, 3] - tt[:, :, 2]).mean().item()
 print(f"ticks per tile {per_tile:.1f}: chain(+issue) {chain:.1f}  finish_tile {fin:.1f}  commit+barrier {bar:.1f}")
-for k in range(14):
+for k in range(NT):
     print(k, f"chain {(tt[:, k, 1]-tt[:, k, 0]).mean().item():.1f} fin {(tt[:, k, 2]-tt[:, k, 1]).mean().item():.1f} bar {(tt[:, k, 3]-tt[:, k, 2]).mean().item():.1f}")
