@@ -14,8 +14,9 @@
 //   * S^T = phi_tile^T . theta_tile on v_mfma_f32_32x32x2_f32: D[row = key][col = query], so each lane
 //     ends up with 16 keys of ONE query -> the row softmax is lane-local: per-lane online state
 //     (running max m, running sum l, 3-vector numerator, running max-affinity and its index);
-//   * keys are additionally split across workgroups (grid.y) to fill 256 CUs; the 2*nsplit partial
-//     states per query are combined by a tiny merge kernel that also writes the x4 nearest upsample.
+//   * the (query block, key tile) work units are dealt out in equal contiguous ranges to 512 workgroups
+//     (stream-K style: 2 resident per CU, same tile count +-1 for every workgroup whatever P is); the
+//     partial states per query are combined by a tiny merge kernel that also writes the x4 upsample.
 // fp32 MFMA (exact fma chain) bounds this kernel: 2*P*P*C flop at 157.3 TFLOP/s -> 88.5 us at P=5184.
 //
 // Softmax arithmetic follows ATen's: s = fl32(f / T) (true IEEE division, so distinct affinities that
@@ -139,9 +140,17 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     const float* blb = a.blab + (long)b * 3 * P;
 
     // query fragment: B[k = 2s+hi][j = l31] for s = 0..127
+    // (unconditional loads from a clamped position, then masked: 128 independent loads in flight)
     float qreg[CORR_C / 2];
+    {
+        const float* tq = th + (unsigned)(hi * P + (qvalid ? query : 0));
 #pragma unroll
-    for (int s = 0; s < CORR_C / 2; ++s) qreg[s] = qvalid ? th[(long)(2 * s + hi) * P + query] : 0.f;
+        for (int s = 0; s < CORR_C / 2; ++s) qreg[s] = tq[(unsigned)(2 * s * P)];
+        if (!qvalid) {
+#pragma unroll
+            for (int s = 0; s < CORR_C / 2; ++s) qreg[s] = 0.f;
+        }
+    }
 
     float m = -INFINITY, l = 0.f, y0 = 0.f, y1 = 0.f, y2 = 0.f, fmax = -INFINITY;
     int amax = 0;
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
   }
 }
 
-// merge the 2*nsplit partial states of each query; write small + x4-upsampled outputs.
+// merge the partial states of each query; write small + x4-upsampled outputs.
 // Workgroup = 64 queries x 4 slot groups: the slot loop is 4x shorter and 4x more loads are in flight
 // than with one thread per query (this kernel is pure L2 latency).
 __global__ __launch_bounds__(256) void corr_merge_kernel(const float* __restrict__ part, int nslot, int P,
