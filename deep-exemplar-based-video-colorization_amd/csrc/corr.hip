@@ -96,6 +96,7 @@ struct CorrArgs {
     long U;                      // work units = B * nqb * ntiles, dealt out evenly to gridDim.x workgroups
     long long* dbg;        // debug timeline (NULL in production): [workgroup][tile][4] s_memtime stamps of wave 0
     int dbg_tiles;
+    int dbg_variant;       // debug only: 1 = skip the softmax arithmetic (timing experiment, wrong results)
 };
 
 // stream-K style decomposition: unit u = (image * nqb + query block) * ntiles + key tile; workgroup w owns the
@@ -273,8 +274,10 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
 #pragma unroll
             for (int s = seg * 8; s < seg * 8 + 8; ++s)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s * CORR_KT], qreg[s], acc, 0, 0, 0);
-            if (seg == 0) rescale();
-            element(seg);
+            if (!a.dbg_variant) {
+                if (seg == 0) rescale();
+                element(seg);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
@@ -438,10 +441,12 @@ extern "C" size_t dvc_corr_workspace_bytes(int32_t B, int32_t P) {
 // stamps of wave 0 of every workgroup into `buf` ([workgroups][max_tiles][4]); pass NULL to switch off.
 static long long* g_corr_dbg = nullptr;
 static int g_corr_dbg_tiles = 0;
+static int g_corr_dbg_variant = 0;
 extern "C" void dvc_debug_corr_timeline(long long* buf, int max_tiles) {
     g_corr_dbg = buf;
     g_corr_dbg_tiles = max_tiles;
 }
+extern "C" void dvc_debug_corr_variant(int v) { g_corr_dbg_variant = v; }
 
 extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* blab, float temperature,
                             float wta_scale, int32_t B, int32_t C, int32_t h, int32_t w, float* y_small,
@@ -458,7 +463,7 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
         DVC_REQUIRE(((reinterpret_cast<uintptr_t>(y_up) | reinterpret_cast<uintptr_t>(sim_up)) & 15) == 0,
                     "dvc_corr_fwd: upsampled outputs must be 16-byte aligned");
     CorrArgs a;
-    a.dbg = g_corr_dbg; a.dbg_tiles = g_corr_dbg_tiles;
+    a.dbg = g_corr_dbg; a.dbg_tiles = g_corr_dbg_tiles; a.dbg_variant = g_corr_dbg_variant;
     a.theta = theta; a.phi = phi; a.blab = blab;
     a.T = temperature; a.invT = 1.0f / temperature; a.wta_scale = wta_scale; a.P = P;
     const CorrPlan pl = corr_plan(B, P);

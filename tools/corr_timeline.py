@@ -19,8 +19,20 @@ P = h * w
 th = ops.corr_prepare(torch.randn(1, 256, P, generator=g).to(dev))
 ph = ops.corr_prepare(torch.randn(1, 256, P, generator=g).to(dev))
 bl = torch.randn(1, 3, P, generator=g).to(dev)
-for _ in range(3):
-    ops.corr_fwd(th, ph, bl, 1e-10, h, w)
+lib.dvc_debug_corr_variant.restype = None
+lib.dvc_debug_corr_variant.argtypes = [ctypes.c_int]
+for variant in (0, 1):
+    lib.dvc_debug_corr_variant(variant)
+    for _ in range(3):
+        ops.corr_fwd(th, ph, bl, 1e-10, h, w)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.corr_fwd(th, ph, bl, 1e-10, h, w)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"variant {variant}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per corr_fwd (+merge)")
+lib.dvc_debug_corr_variant(0)
 MAXT = 16
 nwg = 512
 buf = torch.zeros(nwg * MAXT * 4, dtype=torch.int64, device=dev)
