@@ -197,12 +197,19 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         bl[lbuf * 256 + tid] = blr;
     };
 
-    // ---- online softmax, split so that it runs in the shadow of the next tile's MFMA chain.
-    // All special cases are IEEE arithmetic (no branches): masked keys carry -inf (expf(-inf) = 0),
-    // m_use replaces an all-masked running max of -inf by 0 so (-inf) - (-inf) is never formed.
-    float pv[16];            // pending tile's affinities after WTA / masking
+    // ---- online softmax of the PENDING (previous) tile, run between the MFMA segments of the current one.
+    // ATen computes s = fl32(f / T) (true division) and p = exp(s - max s).  The IEEE division and the
+    // precise expf cost ~25 VALU instructions per affinity, and they are NOT free next to the matrix pipe
+    // when two waves share a SIMD (measured: +37 us per launch).  At T = 1e-10 all but one affinity per row
+    // give p == 0 exactly, so every step is guarded by a cheap WAVE-UNIFORM test and the exact arithmetic
+    // only runs when some lane can actually contribute:
+    //   * mf  = running maximum in the affinity domain (exact), m = fl32(mf / T) its image;
+    //   * an affinity f can have p != 0 only if fl32(f/T) - m > -104; (f - mf) * invT approximates that
+    //     difference to within a few ulp(m), which `slack` covers (ulp(m) ~ 1e3 at T = 1e-10).
+    float pv[16];            // pending tile's affinities after WTA / masking (-inf = masked key)
     float tmax_pend = -INFINITY;
-    float m_use = 0.f;
+    float mf = -INFINITY;    // running max affinity (after WTA), exact
+    float slack = 120.f;
     const float* blp = bl;   // pooled-Lab tile of the pending tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) pv[r] = -INFINITY;
@@ -225,25 +232,33 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         }
         tmax_pend = tilemax;
     };
-    // (2) new running max + rescale of the running sums (true division, as ATen's f / T)
+    // (2) the pending tile raises some lane's running max: new m = fl32(mf/T), rescale the running sums
     auto rescale = [&]() {
-        const float m_new = fmaxf(m, tmax_pend / a.T);
-        m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float sc = expf(m - m_use);  // m == -inf -> 0 (the sums are still 0 then)
-        l *= sc;
-        y0 *= sc;
-        y1 *= sc;
-        y2 *= sc;
-        m = m_new;
+        if (__any(tmax_pend > mf)) {
+            const float mf_new = fmaxf(mf, tmax_pend);
+            const float m_new = mf_new / a.T;                      // true division, as ATen's f / T
+            const float sc = (mf == -INFINITY) ? 0.f : expf(m - m_new);
+            l *= sc;
+            y0 *= sc;
+            y1 *= sc;
+            y2 *= sc;
+            mf = mf_new;
+            m = m_new;
+            slack = 120.f + fabsf(m) * 4.8e-7f;
+        }
     };
-    // (3) one pending affinity: p = exp(f/T - m), accumulate the sum and the colour numerator
+    // (3) one pending affinity: p = exp(fl32(f/T) - m) if it can be non-zero for any lane of the wave
     auto element = [&](int r) {
-        const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float pe = expf(pv[r] / a.T - m_use);
-        l += pe;
-        y0 = fmaf(pe, blp[kl], y0);
-        y1 = fmaf(pe, blp[CORR_KT + kl], y1);
-        y2 = fmaf(pe, blp[2 * CORR_KT + kl], y2);
+        const float f = pv[r];
+        const bool cand = (f - mf) * a.invT > -slack;              // masked keys: -inf -> false
+        if (__any(cand)) {
+            const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float pe = cand ? expf(f / a.T - m) : 0.f;
+            l += pe;
+            y0 = fmaf(pe, blp[kl], y0);
+            y1 = fmaf(pe, blp[CORR_KT + kl], y1);
+            y2 = fmaf(pe, blp[2 * CORR_KT + kl], y2);
+        }
     };
 
     if (t0 < t1) {
