@@ -34,38 +34,46 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// InstanceNorm statistics: one workgroup per (n,c) plane; two passes (mean, then centred sum of
-// squares) with fp64 accumulation — the plane (<= 332 KB) stays in L2 between the passes.
+// InstanceNorm statistics: one workgroup per (n,c) plane, ONE pass: sum and sum of squares accumulated in
+// fp64 (fp32 inputs are exact in fp64 and 53-bit accumulation leaves > 25 bits after the E[x^2]-E[x]^2
+// cancellation for any realistic mean/std ratio; ATen's CPU statistics also accumulate in double).
 __global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __restrict__ x, int C, int HW,
                                                              long x_bs, float eps,
                                                              const float* __restrict__ chan_scale,
                                                              float* __restrict__ scale,
                                                              float* __restrict__ shift) {
-    __shared__ double red[4];
+    __shared__ double red[8];
     const int p = blockIdx.x;  // n*C + c
     const int n = p / C, c = p - n * C;
     const float* xp = x + (long)n * x_bs + (long)c * HW;
     const int tid = threadIdx.x;
-    double s = 0.0;
+    double s = 0.0, q = 0.0;
     const int HW4 = ((reinterpret_cast<uintptr_t>(xp) & 15) == 0) ? (HW & ~3) : 0;
     for (int i = tid * 4; i < HW4; i += 1024) {
         float4 v = *reinterpret_cast<const float4*>(xp + i);
-        s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-    }
-    for (int i = HW4 + tid; i < HW; i += 256) s += (double)xp[i];
-    const double mean = block_sum_d(s, red) / (double)HW;
-    double q = 0.0;
-    for (int i = tid * 4; i < HW4; i += 1024) {
-        float4 v = *reinterpret_cast<const float4*>(xp + i);
-        double a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
-        q += a * a + b * b + cc * cc + d * d;
+        double a = v.x, b = v.y, cc = v.z, d = v.w;
+        s += (a + b) + (cc + d);
+        q += (a * a + b * b) + (cc * cc + d * d);
     }
     for (int i = HW4 + tid; i < HW; i += 256) {
-        double a = xp[i] - mean;
+        double a = xp[i];
+        s += a;
         q += a * a;
     }
-    const double var = block_sum_d(q, red) / (double)HW;
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane == 0) {
+        red[wave] = s;
+        red[4 + wave] = q;
+    }
+    __syncthreads();
     if (tid == 0) {
+        const double S = (red[0] + red[1]) + (red[2] + red[3]);
+        const double Q = (red[4] + red[5]) + (red[6] + red[7]);
+        const double mean = S / (double)HW;
+        double var = Q / (double)HW - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
         double rstd = 1.0 / sqrt(var + (double)eps);
         double sc = rstd * (chan_scale ? (double)chan_scale[c] : 1.0);
         scale[p] = (float)sc;
@@ -231,8 +239,44 @@ extern "C" int dvc_upsample_nearest(const float* x, int32_t planes, int32_t H, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// feature_normalize: per pixel, divide by the L2 norm over channels.  Workgroup = 64 pixels x 4
-// channel groups; pixel axis is the contiguous one so every load/store is a 256-byte row.
+// feature_normalize: per pixel, divide by the L2 norm over channels.  Workgroup = 64 pixels (16 lanes x
+// float4) x 16 channel groups: every load/store is a 256-byte row and 16 channel rows are in flight per
+// wave; the second pass re-reads from L2.
+__global__ __launch_bounds__(256) void channel_l2norm_v4_kernel(const float* __restrict__ x, int C, long HW,
+                                                                float eps, float* __restrict__ y) {
+    __shared__ float4 part[16][16];
+    const int px4 = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const long p = ((long)blockIdx.x * 16 + px4) * 4;
+    const int n = blockIdx.y;
+    const float* xn = x + (long)n * C * HW;
+    float* yn = y + (long)n * C * HW;
+    const bool ok = p < HW;  // HW % 4 == 0
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok)
+        for (int c = g; c < C; c += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(xn + (long)c * HW + p);
+            s.x = fmaf(v.x, v.x, s.x);
+            s.y = fmaf(v.y, v.y, s.y);
+            s.z = fmaf(v.z, v.z, s.z);
+            s.w = fmaf(v.w, v.w, s.w);
+        }
+    part[g][px4] = s;
+    __syncthreads();
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float4 v = part[k][px4];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    const float4 den = make_float4(sqrtf(t.x) + eps, sqrtf(t.y) + eps, sqrtf(t.z) + eps, sqrtf(t.w) + eps);
+    if (ok)
+        for (int c = g; c < C; c += 16) {
+            float4 v = *reinterpret_cast<const float4*>(xn + (long)c * HW + p);
+            v.x /= den.x; v.y /= den.y; v.z /= den.z; v.w /= den.w;
+            *reinterpret_cast<float4*>(yn + (long)c * HW + p) = v;
+        }
+}
+
 __global__ __launch_bounds__(256) void channel_l2norm_kernel(const float* __restrict__ x, int C, long HW,
                                                              float eps, float* __restrict__ y) {
     __shared__ float part[4][64];
@@ -260,7 +304,9 @@ extern "C" int dvc_channel_l2norm(const float* x, int32_t N, int32_t C, int32_t 
                                   dvcStream stream) {
     DVC_REQUIRE(x && y && N > 0 && C > 0 && HW > 0, "dvc_channel_l2norm: bad argument");
     dim3 grid(cdiv(HW, 64), N);
-    hipLaunchKernelGGL(channel_l2norm_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, C, (long)HW, eps, y);
+    const bool v4 = (HW % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+    if (v4) hipLaunchKernelGGL(channel_l2norm_v4_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, C, (long)HW, eps, y);
+    else hipLaunchKernelGGL(channel_l2norm_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, C, (long)HW, eps, y);
     DVC_CHECK_LAUNCH("dvc_channel_l2norm");
     return 0;
 }
