@@ -30,7 +30,9 @@ static int pick_tw(int OW) {
     return best;
 }
 
-// split-K second stage: y = act(sum_s part[s] + bias + residual), fixed summation order (deterministic)
+// split-K second stage: y = act(sum_s part[s] + bias + residual), fixed summation order (deterministic).
+// VEC = 4: one float4 per thread (OHW % 4 == 0 and 16-byte aligned bases), all S partial loads in flight.
+template <int VEC>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ part, int S, long slab,
                                                                  int Cout, long OHW, const float* __restrict__ bias,
                                                                  const float* __restrict__ res, long res_bs,
@@ -40,12 +42,29 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
     const float slope = act_slope_ptr ? *act_slope_ptr : act_slope;
     const long per_img = (long)Cout * OHW;
     const int n = blockIdx.y;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
-        float v = 0.f;
-        for (int s = 0; s < S; ++s) v += part[(long)s * slab + (long)n * per_img + i];
-        if (bias) v += bias[i / OHW];
-        if (res) v += res[(long)n * res_bs + i];
-        y[(long)n * y_bs + i] = apply_act(v, act, slope);
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (i >= per_img) return;
+    float v[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = 0.f;
+    const float* p0 = part + (long)n * per_img + i;
+    if (VEC == 4) {
+        float4 t[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) t[s] = s < S ? *reinterpret_cast<const float4*>(p0 + (long)s * slab) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {   // S <= 4
+            v[0] += t[s].x; v[1] += t[s].y; v[2] += t[s].z; v[3] += t[s].w;
+        }
+    } else {
+        for (int s = 0; s < S; ++s) v[0] += p0[(long)s * slab];
+    }
+    const float b = bias ? bias[i / OHW] : 0.f;   // a float4 never straddles channels (OHW % 4 == 0)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        float o = v[k] + b;
+        if (res) o += res[(long)n * res_bs + i + k];
+        y[(long)n * y_bs + i + k] = apply_act(o, act, slope);
     }
 }
 
@@ -165,9 +184,15 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     DVC_CHECK_LAUNCH("dvc_conv2d");
     if (S > 1) {
         const long OHW = (long)OH * OW, per_img = (long)d->Cout * OHW;
-        int bx = (int)((per_img + 1023) / 1024);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(bx, d->N), dim3(256), 0, s, a.part, S, (long)d->N * per_img,
-                           d->Cout, OHW, bias, residual, a.res_bs, d->act, d->act_slope, act_slope_ptr, y, a.y_bs);
+        const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)d->N * per_img) % 4 == 0);
+        if (v4)
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)((per_img / 4 + 255) / 256), d->N), dim3(256), 0, s,
+                               a.part, S, (long)d->N * per_img, d->Cout, OHW, bias, residual, a.res_bs, d->act,
+                               d->act_slope, act_slope_ptr, y, a.y_bs);
+        else
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3((unsigned)((per_img + 255) / 256), d->N), dim3(256), 0, s,
+                               a.part, S, (long)d->N * per_img, d->Cout, OHW, bias, residual, a.res_bs, d->act,
+                               d->act_slope, act_slope_ptr, y, a.y_bs);
         DVC_CHECK_LAUNCH("dvc_conv2d(split-K reduce)");
     }
     return 0;

@@ -323,6 +323,27 @@ def test_clip_recurrence_cached_equals_uncached_and_deterministic(nets):
         assert torch.equal(x, y) and torch.equal(x, z)
 
 
+def test_batch_of_two_frames_matches_single_frame_runs(nets):
+    """The API is batched (train.py:402 calls it with B=16): a B=2 call must equal two B=1 calls
+    (same kernels, same per-image arithmetic => bit-identical), including the exemplar batch."""
+    from dvc_amd import ops, synth
+    from dvc_amd.frame import VGG_OUT, frame_colorization
+    vgg, warp, col = nets
+    H, W, T = 48, 80, 0.01
+    IB = torch.cat([synth.synth_lab(2, H, W), synth.synth_lab(3, H, W)]).cuda()
+    IA = torch.cat([synth.synth_lab(1000, H, W), synth.synth_lab(1001, H, W)]).cuda()
+    last = torch.cat([synth.synth_lab(7, H, W), synth.synth_lab(8, H, W)]).cuda()
+    fB = vgg(ops.lab2rgb(IB, l_offset=50.0), VGG_OUT)
+    ab2, nl2, fA2 = frame_colorization(IA, IB, last, fB, vgg, warp, col, joint_training=False, temperature=T)
+    assert ab2.shape == (2, 2, H, W) and nl2.shape == (2, 3, H, W) and fA2[0].shape[0] == 2
+    for i in range(2):
+        fBi = vgg(ops.lab2rgb(IB[i:i + 1].contiguous(), l_offset=50.0), VGG_OUT)
+        ab1, nl1, _ = frame_colorization(IA[i:i + 1].contiguous(), IB[i:i + 1].contiguous(), last[i:i + 1].contiguous(),
+                                         fBi, vgg, warp, col, joint_training=False, temperature=T)
+        assert torch.equal(nl2[i:i + 1], nl1), i
+        assert torch.equal(ab2[i:i + 1], ab1), i
+
+
 def test_drop_in_signature_and_loud_cpu_failure(nets):
     import inspect
     from models.FrameColor import frame_colorization, warp_color
