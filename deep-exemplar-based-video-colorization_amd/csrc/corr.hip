@@ -121,8 +121,14 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int P = a.P;
     const long G = gridDim.x;
-    long u = corr_unit_start(blockIdx.x, a.U, G);
-    const long u_end = corr_unit_start(blockIdx.x + 1, a.U, G);
+    // XCD-aware order (speed only): the dispatcher places workgroup b on XCD b % 8, each XCD has its own L2.
+    // Give the workgroups of one XCD CONSECUTIVE unit ranges: they then sweep the same few query blocks,
+    // i.e. the same key tiles at about the same time, and phi is fetched ~once per XCD instead of once
+    // per workgroup.  (bijective for any G: the first G % 8 XCDs get one extra workgroup)
+    const long xq = G / 8, xr = G % 8, xcd = blockIdx.x % 8, xi = blockIdx.x / 8;
+    const long wlog = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    long u = corr_unit_start(wlog, a.U, G);
+    const long u_end = corr_unit_start(wlog + 1, a.U, G);
     long long* dbgh = nullptr;  // debug header slot: [entry, loop start, loop end, exit] of the first segment
     if (a.dbg && tid == 0) {
         dbgh = a.dbg + ((long)blockIdx.x * a.dbg_tiles + (a.dbg_tiles - 1)) * 4;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     const int t0 = (int)(u - (long)qbg * a.ntiles);
     const int t1 = (int)min((long)a.ntiles, t0 + (u_end - u));
     const int b = qbg / a.nqb, qb = qbg - b * a.nqb;
-    const int slot0 = (int)(blockIdx.x - corr_unit_owner((long)qbg * a.ntiles, a.U, G)) * 2;
+    const int slot0 = (int)(wlog - corr_unit_owner((long)qbg * a.ntiles, a.U, G)) * 2;
     const int query = qb * CORR_QB + wave * 32 + l31;
     const bool qvalid = query < P;
     const float* th = a.theta + (long)b * CORR_C * P;
