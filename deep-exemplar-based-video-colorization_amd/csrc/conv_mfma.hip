@@ -49,11 +49,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
     for (int k = 0; k < VEC; ++k) v[k] = 0.f;
     const float* p0 = part + (long)n * per_img + i;
     if (VEC == 4) {
-        float4 t[4];
+        float4 t[8];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) t[s] = s < S ? *reinterpret_cast<const float4*>(p0 + (long)s * slab) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < 8; ++s) t[s] = s < S ? *reinterpret_cast<const float4*>(p0 + (long)s * slab) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {   // S <= 4
+        for (int s = 0; s < 8; ++s) {   // S <= 8, fixed order
             v[0] += t[s].x; v[1] += t[s].y; v[2] += t[s].z; v[3] += t[s].w;
         }
     } else {
@@ -167,7 +167,8 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     int S = 1;
     if (workspace && d->split_k != 1 && waves < 1536 && nchunks >= 4) {
         S = d->split_k > 1 ? d->split_k : (int)((2048 + waves - 1) / waves);
-        if (S > 4) S = 4;
+        if (d->split_k <= 1 && S > 4) S = 4;   // the static heuristic stays conservative; deeper splits are for the tuner
+        if (S > 8) S = 8;
         if (S > nchunks / 2) S = nchunks / 2;
         while (S > 1 && (size_t)S * d->N * d->Cout * OH * OW * sizeof(float) > workspace_bytes) --S;
     }

@@ -88,7 +88,7 @@ def _save_tuned():
 def autotune_table():
     return dict(_tuned)
 
-CONV_WORKSPACE_BYTES = 32 << 20   # split-K scratch: 4 x the largest under-filled layer output
+CONV_WORKSPACE_BYTES = 64 << 20   # split-K scratch: up to 8 partial copies of an under-filled layer's output
 
 
 def pack_conv_weight(w):
@@ -163,7 +163,7 @@ def _tune_conv(lib, d, tensors):
     best, best_t = (-1, 0), float("inf")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for cfg in range(5):
-        for sk in (1, 2, 3, 4):
+        for sk in (1, 2, 3, 4, 6, 8):
             d.cfg, d.split_k = cfg, sk
             if launch() != 0:          # configuration does not fit this geometry
                 break

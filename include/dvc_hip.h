@@ -75,7 +75,7 @@ typedef struct DvcConvDesc {
     float   act_slope;          /* PReLU/LeakyReLU slope when act_slope_ptr == NULL */
     int32_t in_prelu;           /* apply PReLU (slope *in_slope_ptr) to the affine-transformed input */
     int32_t cfg;                /* tile configuration; -1 = choose automatically */
-    int32_t split_k;            /* 0 = automatic, 1 = off, 2..4 = forced (needs a workspace) */
+    int32_t split_k;            /* 0 = automatic, 1 = off, 2..8 = forced (needs a workspace) */
     int64_t x_batch_stride;     /* elements; 0 => Cin*H*W */
     int64_t y_batch_stride;     /* elements; 0 => Cout*OH*OW  (lets y be a channel slice) */
     int64_t res_batch_stride;   /* elements; 0 => Cout*OH*OW */

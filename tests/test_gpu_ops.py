@@ -117,7 +117,7 @@ def test_conv2d(ops, case, cfg):
     assert e < 2e-5, (name, cfg, e)  # fp32 accumulation over <= 2304 terms
 
 
-@pytest.mark.parametrize("split_k", [1, 2, 3, 4])
+@pytest.mark.parametrize("split_k", [1, 2, 3, 4, 6, 8])
 def test_conv2d_split_k(ops, split_k):
     """Split-K (partial sums + fixed-order reduce) gives the same result as the single-pass kernel, with
     bias / residual / activation / input affine, a channel-slice destination and batch 2."""
