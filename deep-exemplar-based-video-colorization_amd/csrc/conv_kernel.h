@@ -28,6 +28,8 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CONV_AS1 __attribute__((address_space(1)))
+#define CONV_AS3 __attribute__((address_space(3)))
 
 #define CONV_EPT_GEN 12  // staged input elements per thread in the run-time-geometry variant
 #define CONV_MAX_AFFINE_CIN 512  // static LDS affine table of the compile-time-geometry variants
@@ -127,8 +129,16 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     }
 }
 
-template <int WM, int WN, int RM, int RN, int TW, int KS, int DIL, bool GEN>
+// DMA = true ("plain" layers: no input affine / PReLU, Cin % CK == 0, Cout % MT == 0, compile-time
+// geometry): the patch and the weight slice go global -> LDS by LDS-DMA (global_load_lds), no staging
+// registers, no commit phase and (almost) no VALU in the chunk loop.  That matters more than it would on
+// other matrix pipes: the fp32 MFMA shares the SIMD's fp32 lanes with ordinary VALU work (vector and
+// matrix fp32 peaks are the same number), so every staging VALU instruction is taken from the MFMA rate.
+// The LDS patch image is then linear in the staged element index (pitch padding included); cells that
+// read padding zeros are zeroed once and never written again (their lanes are masked off in the DMA).
+template <int WM, int WN, int RM, int RN, int TW, int KS, int DIL, bool GEN, bool DMA = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a) {
+    static_assert(!(GEN && DMA), "LDS-DMA staging needs compile-time geometry");
     constexpr int NT = 64 * WM * WN;
     constexpr int MT = 32 * WM * RM;
     constexpr int RPT = 32 / TW;  // rows per 32-pixel N-tile
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
     constexpr int C_IH = PH + DIL * (KS - 1);
     constexpr int C_IW = TW + DIL * (KS - 1);
     constexpr int C_IWP = conv_pitch(TW, C_IW, 1);
-    constexpr int EPT = GEN ? CONV_EPT_GEN : (CK * C_IH * C_IW + NT - 1) / NT;
+    constexpr int EPT = GEN ? CONV_EPT_GEN : DMA ? (CK * C_IH * C_IWP + NT - 1) / NT : (CK * C_IH * C_IW + NT - 1) / NT;
 
     const int stride = GEN ? a.stride : 1;
     const int dil = GEN ? a.dil : DIL;
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
     constexpr int ws_floats = conv_ws_floats(CK, KK, MT);
     constexpr int C_XS = GEN ? 4 : conv_xs_floats(CK, C_IH, C_IWP);
     constexpr int C_WS = GEN ? 4 : ws_floats;
-    constexpr int AFF_MAX = GEN ? 4 : 2 * (CONV_MAX_AFFINE_CIN + 16);
+    constexpr int AFF_MAX = (GEN || DMA) ? 4 : 2 * (CONV_MAX_AFFINE_CIN + 16);
     __shared__ __attribute__((aligned(16))) float s_xs0[C_XS];
     __shared__ __attribute__((aligned(16))) float s_xs1[C_XS];
     __shared__ __attribute__((aligned(16))) float s_ws0[C_WS];
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
     float* const aff = GEN ? smem + 2 * xs_floats + 2 * ws_floats : s_aff;  // [2][cin_pad + CK]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_x = (a.OW + TW - 1) / TW;
@@ -199,7 +209,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
         int e = tid + t * NT;
-        if (e < total) {
+        if (DMA) {  // element e of the PITCHED image [CK][IH_T][IW_P]; LDS float offset == e
+            int c = e / plane;
+            int rem = e - c * plane;
+            int iy = rem / IW_P, ix = rem - iy * IW_P;
+            int g = (e < CK * plane && ix < IW_T) ? stored_offset(a, vy0 + iy, vx0 + ix) : -1;
+            gofs[t] = g >= 0 ? c * HWi + g : -1;
+            lofs[t] = 0;
+        } else if (e < total) {
             int c = e / tile_elems;
             int rem = e - c * tile_elems;
             int iy = rem / IW_T, ix = rem - iy * IW_T;
@@ -262,6 +279,32 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
         }
     };
 
+    // LDS-DMA staging of chunk `ci` (DMA variants): every lane supplies its own global address, the LDS
+    // destination is wave-uniform base + lane * size.
+    auto issue_dma = [&](int ci, float* xs, float* ws) {
+        const float* xc = xn + (long)ci * CK * HWi;
+        const float* wc = a.w + (long)ci * CK * KK * a.Cout;
+#pragma unroll
+        for (int t = 0; t < EPT; ++t)
+            if (gofs[t] >= 0)
+                __builtin_amdgcn_global_load_lds((const CONV_AS1 void*)(xc + (unsigned)gofs[t]),
+                                                 (CONV_AS3 void*)(xs + t * NT + wave * 64), 4, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            if (wofs[i] >= 0)
+                __builtin_amdgcn_global_load_lds((const CONV_AS1 void*)(wc + (unsigned)wofs[i]),
+                                                 (CONV_AS3 void*)(ws + (i * NT + wave * 64) * 4), 16, 0, 0);
+    };
+
+    if (DMA) {
+        for (int i = tid; i < C_XS / 4; i += NT) {
+            reinterpret_cast<float4*>(xsb0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            reinterpret_cast<float4*>(xsb1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        issue_dma(c_begin, xsb0, wsb0);
+        __syncthreads();  // (drains the DMA: vmcnt(0) before the barrier)
+    } else {
     issue(c_begin);
     if (affine) {
         const float* scn = a.in_scale + (long)n * a.Cin;
@@ -275,6 +318,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
     commit(c_begin, xsb0, wsb0);
     issue(min(c_begin + 1, nchunks - 1));
     __syncthreads();
+    }
 
     // tot: running sum; acc: one chunk's MFMA chain.  Flushing per chunk keeps every fp32 chain short
     // (CK*ks*ks terms) and makes the total a sum of Cin/CK partials — blocked summation.
@@ -300,8 +344,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
     // asked (sched_group_barrier) to spread the staging instructions between the MFMAs.  Past the
     // last chunk the clamped indices re-stage the last chunk: harmless.
     auto chunk = [&](int ci, const float* xs, const float* ws, float* xs_next, float* ws_next) {
-        commit(min(ci + 1, nchunks - 1), xs_next, ws_next);
-        issue(min(ci + 2, nchunks - 1));
+        if (DMA) {
+            if (ci + 1 < nchunks) issue_dma(ci + 1, xs_next, ws_next);
+        } else {
+            commit(min(ci + 1, nchunks - 1), xs_next, ws_next);
+            issue(min(ci + 2, nchunks - 1));
+        }
         const float* wb = ws + woff;
 #pragma unroll
         for (int i = 0; i < RM; ++i)
@@ -333,6 +381,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
         for (int i = 0; i < KK * (CK / 2) * RM * RN; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+            if (DMA) continue;
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
             if ((i & 3) == 0) {
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
@@ -401,24 +450,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
 }
 
 // ---- per-variant launchers (one translation unit each, so they compile in parallel)
-template <int KS, int DIL, bool GEN, int WM, int WN, int RM, int RN>
+template <int KS, int DIL, bool GEN, bool DMA, int WM, int WN, int RM, int RN>
 static void conv_launch_tw(int tw, dim3 grid, size_t lds, hipStream_t s, const ConvKArgs& a) {
     constexpr int NT = 64 * WM * WN;
     switch (tw) {
-        case 32: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 32, KS, DIL, GEN>), grid, dim3(NT), lds, s, a); break;
-        case 16: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 16, KS, DIL, GEN>), grid, dim3(NT), lds, s, a); break;
-        default: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 8, KS, DIL, GEN>), grid, dim3(NT), lds, s, a); break;
+        case 32: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 32, KS, DIL, GEN, DMA>), grid, dim3(NT), lds, s, a); break;
+        case 16: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 16, KS, DIL, GEN, DMA>), grid, dim3(NT), lds, s, a); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, RM, RN, 8, KS, DIL, GEN, DMA>), grid, dim3(NT), lds, s, a); break;
     }
 }
 
-template <int KS, int DIL, bool GEN>
+template <int KS, int DIL, bool GEN, bool DMA = false>
 static void conv_launch_variant(int cfg, int tw, dim3 grid, size_t lds, hipStream_t s, const ConvKArgs& a) {
     switch (cfg) {
-        case 0: conv_launch_tw<KS, DIL, GEN, 1, 4, 2, 2>(tw, grid, lds, s, a); break;
-        case 1: conv_launch_tw<KS, DIL, GEN, 1, 4, 1, 2>(tw, grid, lds, s, a); break;
-        case 2: conv_launch_tw<KS, DIL, GEN, 1, 4, 2, 1>(tw, grid, lds, s, a); break;
-        case 3: conv_launch_tw<KS, DIL, GEN, 1, 4, 1, 1>(tw, grid, lds, s, a); break;
-        default: conv_launch_tw<KS, DIL, GEN, 2, 2, 1, 1>(tw, grid, lds, s, a); break;
+        case 0: conv_launch_tw<KS, DIL, GEN, DMA, 1, 4, 2, 2>(tw, grid, lds, s, a); break;
+        case 1: conv_launch_tw<KS, DIL, GEN, DMA, 1, 4, 1, 2>(tw, grid, lds, s, a); break;
+        case 2: conv_launch_tw<KS, DIL, GEN, DMA, 1, 4, 2, 1>(tw, grid, lds, s, a); break;
+        case 3: conv_launch_tw<KS, DIL, GEN, DMA, 1, 4, 1, 1>(tw, grid, lds, s, a); break;
+        default: conv_launch_tw<KS, DIL, GEN, DMA, 2, 2, 1, 1>(tw, grid, lds, s, a); break;
     }
 }
 
@@ -426,3 +475,6 @@ void conv_launch_k3d1(int cfg, int tw, dim3 grid, size_t lds, hipStream_t s, con
 void conv_launch_k3d2(int cfg, int tw, dim3 grid, size_t lds, hipStream_t s, const ConvKArgs& a);
 void conv_launch_k1(int cfg, int tw, dim3 grid, size_t lds, hipStream_t s, const ConvKArgs& a);
 void conv_launch_gen(int cfg, int tw, dim3 grid, size_t lds, hipStream_t s, const ConvKArgs& a);
+void conv_launch_k3d1_dma(int cfg, int tw, dim3 grid, size_t lds, hipStream_t s, const ConvKArgs& a);
+void conv_launch_k3d2_dma(int cfg, int tw, dim3 grid, size_t lds, hipStream_t s, const ConvKArgs& a);
+void conv_launch_k1_dma(int cfg, int tw, dim3 grid, size_t lds, hipStream_t s, const ConvKArgs& a);

@@ -128,6 +128,11 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     };
     if (gen) DVC_REQUIRE(d->ksize == 3, "dvc_conv2d: stride-2 / dilated variant supports ksize 3 only");
     int cfg = d->cfg;
+    bool allow_dma = true;
+    if (cfg >= 16) {  // 16 + tile configuration: force register staging (autotuner / A-B measurements)
+        cfg -= 16;
+        allow_dma = false;
+    }
     if (cfg < 0) {
         // Cost model fitted to the per-layer sweep (profiles/r01_conv_layer_sweep.json): a layer takes
         // (32x32 MFMA tiles per wave, padding included) x (waves per SIMD, at least one round) x a
@@ -178,7 +183,13 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     a.part = reinterpret_cast<float*>(workspace);
     dim3 grid(cdiv(OW, tw) * cdiv(OH, ph), cdiv(d->Cout, mt), d->N * S);
     hipStream_t s = (hipStream_t)stream;
-    if (gen) conv_launch_gen(cfg, tw, grid, lds, s, a);
+    // "plain" layers stage through LDS-DMA (see conv_kernel.h)
+    const bool dma = allow_dma && !gen && !in_scale && !d->in_prelu && d->Cin % ck == 0 && d->Cout % mt == 0;
+    if (dma) {
+        if (d->ksize == 1) conv_launch_k1_dma(cfg, tw, grid, lds, s, a);
+        else if (d->dil == 1) conv_launch_k3d1_dma(cfg, tw, grid, lds, s, a);
+        else conv_launch_k3d2_dma(cfg, tw, grid, lds, s, a);
+    } else if (gen) conv_launch_gen(cfg, tw, grid, lds, s, a);
     else if (d->ksize == 1) conv_launch_k1(cfg, tw, grid, lds, s, a);
     else if (d->dil == 1) conv_launch_k3d1(cfg, tw, grid, lds, s, a);
     else conv_launch_k3d2(cfg, tw, grid, lds, s, a);

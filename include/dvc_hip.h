@@ -74,7 +74,9 @@ typedef struct DvcConvDesc {
     int32_t act;                /* DVC_ACT_* */
     float   act_slope;          /* PReLU/LeakyReLU slope when act_slope_ptr == NULL */
     int32_t in_prelu;           /* apply PReLU (slope *in_slope_ptr) to the affine-transformed input */
-    int32_t cfg;                /* tile configuration; -1 = choose automatically */
+    int32_t cfg;                /* tile configuration 0..4; -1 = choose automatically; 16 + k = configuration k
+                                   with register staging forced (layers without a fused input transform
+                                   otherwise stage through LDS-DMA) */
     int32_t split_k;            /* 0 = automatic, 1 = off, 2..8 = forced (needs a workspace) */
     int64_t x_batch_stride;     /* elements; 0 => Cin*H*W */
     int64_t y_batch_stride;     /* elements; 0 => Cout*OH*OW  (lets y be a channel slice) */

@@ -74,11 +74,17 @@ CONV_CASES = [
     ("leaky", 1, 16, 32, 20, 33, 3, 1, 1, 1, 0, 1, 1, False, False, False, 3),
     ("prelu_out", 1, 16, 32, 9, 7, 3, 1, 1, 1, 1, 1, 1, False, False, True, 2),
     ("cin7", 1, 7, 32, 24, 40, 3, 1, 1, 1, 0, 1, 1, False, False, False, 1),
+    # layers without a fused input transform (Cin % 8 == 0, Cout % 64 == 0): LDS-DMA staging
+    ("plain_up", 1, 32, 64, 13, 24, 3, 1, 1, 1, 0, 2, 1, False, False, True, 1),
+    ("plain_sub", 1, 16, 64, 54, 96, 3, 1, 1, 1, 0, 1, 2, False, False, False, 1),
+    ("plain_dil2", 2, 32, 64, 27, 48, 3, 1, 2, 2, 0, 1, 1, False, False, False, 1),
+    ("plain_wide", 1, 24, 128, 21, 100, 3, 1, 1, 1, 0, 1, 1, False, False, False, 3),
+    ("plain_k1", 1, 64, 64, 31, 17, 1, 1, 1, 0, 0, 1, 1, False, False, True, 0),
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 16, 18, 20])   # 16 + k: register staging forced
 def test_conv2d(ops, case, cfg):
     (name, N, Cin, Cout, H, W, ks, stride, dil, pad, pad_mode, in_up, in_sub, affine, in_prelu, use_res, act) = case
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)

@@ -49,7 +49,8 @@ for k, (r, count) in uniq.items():
         res = torch.randn(r["N"], r["Cout"], OH, OW, device=dev)
     out = torch.empty(r["N"], r["Cout"], OH, OW, device=dev)
     times = {}
-    for cfg in (-1, 0, 1, 2, 3, 4):
+    plain = not r["affine"] and not r["in_prelu"]
+    for cfg in (-1, 0, 1, 2, 3, 4) + ((16, 17, 18, 19, 20) if plain else ()):   # 16+k: register staging forced
         def run():
             ops.conv2d(x, w, b, ksize=r["ksize"], stride=r["stride"], dil=r["dil"], pad=r["pad"],
                        pad_mode=r["pad_mode"], in_up=r["in_up"], in_sub=r["in_sub"], act=r["act"], act_slope=0.2,
@@ -94,7 +95,7 @@ json.dump(dict(H=H, W=W, total_us_auto=tot_auto, total_us_best=tot_best, layers=
 print(f"conv time per frame: auto {tot_auto / 1e3:.2f} ms, best-per-layer {tot_best / 1e3:.2f} ms")
 for d in results[:45]:
     s = d["shape"]
-    print(f'{d["count"]}x Cin={s["Cin"]:3d} Cout={s["Cout"]:3d} {s["H"]}x{s["W"]}->{d["OH"]}x{d["OW"]} k{s["ksize"]} s{s["stride"]} d{s["dil"]} '
+    print(f'{d["count"]}x {"plain" if not s["affine"] and not s["in_prelu"] else "xform"} Cin={s["Cin"]:3d} Cout={s["Cout"]:3d} {s["H"]}x{s["W"]}->{d["OH"]}x{d["OW"]} k{s["ksize"]} s{s["stride"]} d{s["dil"]} '
           f'up{s["in_up"]} sub{s["in_sub"]}: auto {d["us"][-1]:.0f}us ({d["tflops_auto"]:.1f} TF) best cfg{d["best"]} '
           f'{d["us"][d["best"]]:.0f}us ({d["tflops_best"]:.1f} TF) all=' + " ".join(
               f'{c}:{(t if t else 0):.0f}' for c, t in d["us"].items() if c != -1))
