@@ -37,58 +37,167 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 // InstanceNorm statistics: one workgroup per (n,c) plane, ONE pass: sum and sum of squares accumulated in
 // fp64 (fp32 inputs are exact in fp64 and 53-bit accumulation leaves > 25 bits after the E[x^2]-E[x]^2
 // cancellation for any realistic mean/std ratio; ATen's CPU statistics also accumulate in double).
-__global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __restrict__ x, int C, int HW,
-                                                             long x_bs, float eps,
-                                                             const float* __restrict__ chan_scale,
-                                                             float* __restrict__ scale,
-                                                             float* __restrict__ shift) {
-    __shared__ double red[8];
-    const int p = blockIdx.x;  // n*C + c
-    const int n = p / C, c = p - n * C;
-    const float* xp = x + (long)n * x_bs + (long)c * HW;
-    const int tid = threadIdx.x;
+// Works for any block size that is a multiple of 64 up to 1024; every thread returns the plane's
+// (scale, shift) = (rstd * chan_scale, -mean * scale).
+__device__ __forceinline__ void plane_stats(const float* __restrict__ xp, int HW, float eps, float cs,
+                                            double* red /* [34] */, float* sc_out, float* sh_out) {
+    const int tid = threadIdx.x, nt = blockDim.x;
     double s = 0.0, q = 0.0;
     const int HW4 = ((reinterpret_cast<uintptr_t>(xp) & 15) == 0) ? (HW & ~3) : 0;
-    for (int i = tid * 4; i < HW4; i += 1024) {
+    for (int i = tid * 4; i < HW4; i += nt * 4) {
         float4 v = *reinterpret_cast<const float4*>(xp + i);
         double a = v.x, b = v.y, cc = v.z, d = v.w;
         s += (a + b) + (cc + d);
         q += (a * a + b * b) + (cc * cc + d * d);
     }
-    for (int i = HW4 + tid; i < HW; i += 256) {
+    for (int i = HW4 + tid; i < HW; i += nt) {
         double a = xp[i];
         s += a;
         q += a * a;
     }
     s = wave_sum_d(s);
     q = wave_sum_d(q);
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     if (lane == 0) {
         red[wave] = s;
-        red[4 + wave] = q;
+        red[16 + wave] = q;
     }
     __syncthreads();
     if (tid == 0) {
-        const double S = (red[0] + red[1]) + (red[2] + red[3]);
-        const double Q = (red[4] + red[5]) + (red[6] + red[7]);
+        double S = 0.0, Q = 0.0;
+        for (int i = 0; i < nw; ++i) {
+            S += red[i];
+            Q += red[16 + i];
+        }
         const double mean = S / (double)HW;
         double var = Q / (double)HW - mean * mean;
         var = var < 0.0 ? 0.0 : var;
-        double rstd = 1.0 / sqrt(var + (double)eps);
-        double sc = rstd * (chan_scale ? (double)chan_scale[c] : 1.0);
-        scale[p] = (float)sc;
-        shift[p] = (float)(-mean * sc);
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double sc = rstd * (double)cs;
+        red[32] = sc;
+        red[33] = -mean * sc;
+    }
+    __syncthreads();
+    *sc_out = (float)red[32];
+    *sh_out = (float)red[33];
+}
+
+__global__ __launch_bounds__(1024) void instnorm_stats_kernel(const float* __restrict__ x, int C, int HW,
+                                                              long x_bs, float eps,
+                                                              const float* __restrict__ chan_scale,
+                                                              float* __restrict__ scale,
+                                                              float* __restrict__ shift) {
+    __shared__ double red[34];
+    const int p = blockIdx.x;  // n*C + c
+    const int n = p / C, c = p - n * C;
+    float sc, sh;
+    plane_stats(x + (long)n * x_bs + (long)c * HW, HW, eps, chan_scale ? chan_scale[c] : 1.f, red, &sc, &sh);
+    if (threadIdx.x == 0) {
+        scale[p] = sc;
+        shift[p] = sh;
     }
 }
+
+// threads per plane: enough loads in flight for the large (full-resolution) planes
+static int instnorm_block(int HW) { return HW >= 32768 ? 1024 : HW >= 8192 ? 512 : 256; }
 
 extern "C" int dvc_instnorm_stats(const float* x, int32_t N, int32_t C, int32_t HW,
                                   int64_t x_batch_stride, float eps, const float* chan_scale,
                                   float* scale, float* shift, dvcStream stream) {
     DVC_REQUIRE(x && scale && shift && N > 0 && C > 0 && HW > 0, "dvc_instnorm_stats: bad argument");
     long bs = x_batch_stride ? x_batch_stride : (long)C * HW;
-    hipLaunchKernelGGL(instnorm_stats_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream, x, C, HW,
-                       bs, eps, chan_scale, scale, shift);
+    hipLaunchKernelGGL(instnorm_stats_kernel, dim3(N * C), dim3(instnorm_block(HW)), 0, (hipStream_t)stream,
+                       x, C, HW, bs, eps, chan_scale, scale, shift);
     DVC_CHECK_LAUNCH("dvc_instnorm_stats");
+    return 0;
+}
+
+// InstanceNorm + what follows it, one launch: the workgroup that reduced the plane also applies
+// y = prelu_or_id(x*scale + shift + residual) to it (second read from L2), with the output index maps of
+// affine_act_kernel plus stride-`sub` subsampling.
+__global__ __launch_bounds__(1024) void instnorm_apply_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ res,
+                                                              const float* __restrict__ slope_ptr,
+                                                              const float* __restrict__ chan_scale, float eps,
+                                                              int C, int H, int W, int up, int sub, int rpad,
+                                                              long x_bs, long res_bs, long y_bs,
+                                                              float* __restrict__ y, float* __restrict__ scale,
+                                                              float* __restrict__ shift) {
+    __shared__ double red[34];
+    const int p = blockIdx.x;  // n*C + c
+    const int n = p / C, c = p - n * C;
+    const float* xp = x + (long)n * x_bs + (long)c * H * W;
+    float sc, sh;
+    plane_stats(xp, H * W, eps, chan_scale ? chan_scale[c] : 1.f, red, &sc, &sh);
+    if (threadIdx.x == 0 && scale) {
+        scale[p] = sc;
+        shift[p] = sh;
+    }
+    const bool has_act = slope_ptr != nullptr;
+    const float slope = has_act ? *slope_ptr : 1.f;
+    const float* rp = res ? res + (long)n * res_bs + (long)c * H * W : nullptr;
+    const int VH = sub == 2 ? (H + 1) / 2 : H * up, VW = sub == 2 ? (W + 1) / 2 : W * up;
+    const int OH = VH + 2 * rpad, OW = VW;
+    float* yp = y + (long)n * y_bs + (long)c * OH * OW;
+    const int total = OH * OW, nt = blockDim.x;
+    if (up == 1 && sub == 1 && rpad == 0) {  // elementwise (possibly in place): float4 when aligned
+        const bool v4 = ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp) |
+                          reinterpret_cast<uintptr_t>(rp)) & 15) == 0;
+        const int T4 = v4 ? (total & ~3) : 0;
+        for (int i = threadIdx.x * 4; i < T4; i += nt * 4) {
+            float4 v = *reinterpret_cast<const float4*>(xp + i);
+            float o[4] = {v.x * sc + sh, v.y * sc + sh, v.z * sc + sh, v.w * sc + sh};
+            if (rp) {
+                float4 r = *reinterpret_cast<const float4*>(rp + i);
+                o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+            }
+            if (has_act) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = o[k] >= 0.f ? o[k] : o[k] * slope;
+            }
+            *reinterpret_cast<float4*>(yp + i) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        for (int i = T4 + threadIdx.x; i < total; i += nt) {
+            float v = xp[i] * sc + sh;
+            if (rp) v += rp[i];
+            if (has_act) v = v >= 0.f ? v : v * slope;
+            yp[i] = v;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < total; i += nt) {
+        int oy = i / OW, ox = i - oy * OW;
+        int uy = oy - rpad;
+        uy = uy < 0 ? 0 : (uy >= VH ? VH - 1 : uy);
+        int sy = sub == 2 ? uy * 2 : (up == 1 ? uy : uy / up);
+        int sx = sub == 2 ? ox * 2 : (up == 1 ? ox : ox / up);
+        float v = xp[sy * W + sx] * sc + sh;
+        if (rp) v += rp[sy * W + sx];
+        if (has_act) v = v >= 0.f ? v : v * slope;
+        yp[i] = v;
+    }
+}
+
+extern "C" int dvc_instnorm_apply(const float* x, const float* residual, const float* slope_ptr,
+                                  const float* chan_scale, float eps, int32_t N, int32_t C, int32_t H,
+                                  int32_t W, int32_t up, int32_t sub, int32_t rpad, int64_t x_batch_stride,
+                                  int64_t res_batch_stride, int64_t y_batch_stride, float* y,
+                                  float* scale_out, float* shift_out, dvcStream stream) {
+    DVC_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0, "dvc_instnorm_apply: bad argument");
+    DVC_REQUIRE(up >= 1 && up <= 4 && (sub == 1 || sub == 2) && rpad >= 0 && !(up != 1 && sub != 1),
+                "dvc_instnorm_apply: bad up/sub/rpad");
+    DVC_REQUIRE(!(residual && (up != 1 || sub != 1)), "dvc_instnorm_apply: residual requires up == sub == 1");
+    DVC_REQUIRE((scale_out == nullptr) == (shift_out == nullptr), "dvc_instnorm_apply: scale/shift come together");
+    DVC_REQUIRE(!(x == y && (up != 1 || sub != 1 || rpad != 0)), "dvc_instnorm_apply: in place needs up == sub == 1, rpad == 0");
+    const long VH = sub == 2 ? (H + 1) / 2 : (long)H * up, VW = sub == 2 ? (W + 1) / 2 : (long)W * up;
+    const long OH = VH + 2 * rpad, OW = VW;
+    long xbs = x_batch_stride ? x_batch_stride : (long)C * H * W;
+    long rbs = res_batch_stride ? res_batch_stride : (long)C * H * W;
+    long ybs = y_batch_stride ? y_batch_stride : (long)C * OH * OW;
+    hipLaunchKernelGGL(instnorm_apply_kernel, dim3(N * C), dim3(instnorm_block(H * W)), 0, (hipStream_t)stream,
+                       x, residual, slope_ptr, chan_scale, eps, C, H, W, up, sub, rpad, xbs, rbs, ybs, y,
+                       scale_out, shift_out);
+    DVC_CHECK_LAUNCH("dvc_instnorm_apply");
     return 0;
 }
 

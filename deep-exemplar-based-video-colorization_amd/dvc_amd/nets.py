@@ -180,25 +180,31 @@ class WarpNet(nn.Module):
             (ia, _, _, _, pa), (ib, _, _, sb, pb) = spec["convs"]
             ca, cb = seq[ia], seq[ib]
             t = ops.conv2d(x, self._pk(f"{name}.{ia}", ca), ca.bias.detach(), pad_mode=ops.PAD_REFLECT)
-            sc, sh = ops.instnorm_stats(t)
-            t = ops.conv2d(t, self._pk(f"{name}.{ib}", cb), cb.bias.detach(), stride=sb,
-                           pad_mode=ops.PAD_REFLECT, in_up=2 if spec["up_mid"] else 1,
-                           in_scale=sc, in_shift=sh, in_slope_t=seq[pa].weight.detach())
-            sc, sh = ops.instnorm_stats(t)
+            # InstanceNorm + PReLU are materialised (one launch, in place) so that the next convolution
+            # has no fused input transform and stages through LDS-DMA; the stride-2 convolution
+            # (run-time-geometry kernel, register staging anyway) applies them on load instead
+            if sb == 1:
+                ops.instnorm_apply(t, slope_t=seq[pa].weight.detach(), out=t)
+                t = ops.conv2d(t, self._pk(f"{name}.{ib}", cb), cb.bias.detach(), pad_mode=ops.PAD_REFLECT,
+                               in_up=2 if spec["up_mid"] else 1)
+            else:
+                sc, sh = ops.instnorm_stats(t)
+                t = ops.conv2d(t, self._pk(f"{name}.{ib}", cb), cb.bias.detach(), stride=sb,
+                               pad_mode=ops.PAD_REFLECT, in_up=2 if spec["up_mid"] else 1,
+                               in_scale=sc, in_shift=sh, in_slope_t=seq[pa].weight.detach())
             dst = trunk[:, i * arch.WARP_FEATURE_CH:(i + 1) * arch.WARP_FEATURE_CH]
-            ops.affine_act(t, sc, sh, slope_t=seq[pb].weight.detach(), up=2 if spec["up_out"] else 1,
-                           rpad=rpad5 if name == "layer5_1" else 0, out=dst, out_batch_stride=bs)
+            ops.instnorm_apply(t, slope_t=seq[pb].weight.detach(), up=2 if spec["up_out"] else 1,
+                               rpad=rpad5 if name == "layer5_1" else 0, out=dst, out_batch_stride=bs)
         x = trunk
         for b in range(arch.WARP_NUM_RESBLOCKS):
             blk = self.layer[b]
             a = blk.prelu.weight.detach()
             t = ops.conv2d(x, self._pk(f"layer.{b}.conv1", blk.conv1), blk.conv1.bias.detach(),
                            pad_mode=ops.PAD_REFLECT)
-            sc, sh = ops.instnorm_stats(t)
+            ops.instnorm_apply(t, slope_t=a, out=t)
             t = ops.conv2d(t, self._pk(f"layer.{b}.conv2", blk.conv2), blk.conv2.bias.detach(),
-                           pad_mode=ops.PAD_REFLECT, in_scale=sc, in_shift=sh, in_slope_t=a)
-            sc, sh = ops.instnorm_stats(t)
-            x = ops.affine_act(t, sc, sh, residual=x, slope_t=a)
+                           pad_mode=ops.PAD_REFLECT)
+            x = ops.instnorm_apply(t, residual=x, slope_t=a, out=t)
         return x
 
     def project(self, which, feats, bf16=False):
@@ -305,17 +311,18 @@ class ColorVidNet(nn.Module):
         _check_input(x, "ColorVidNet")
         x = x.detach().contiguous().float()
         acts = {"x": x}
-        stats = {}
+        normed = {}
 
         def norm_of(src, ss_key=None):
+            """InstanceNorm2d(src) [* the depthwise `_ss` weight, stride 2] as a tensor (ColorVidNet.py:85-94,12)."""
             k = (src, ss_key)
-            if k not in stats:
+            if k not in normed:
                 cs = None
                 if ss_key is not None:
                     ssw = self._mod(ss_key).weight
                     cs = self._cache.get(ss_key, ssw, lambda w: w.detach().reshape(-1).contiguous())
-                stats[k] = ops.instnorm_stats(acts[src], eps=1e-5, chan_scale=cs)
-            return stats[k]
+                normed[k] = ops.instnorm_apply(acts[src], eps=1e-5, chan_scale=cs, sub=2 if ss_key else 1)
+            return normed[k]
 
         act_map = {"relu": ops.ACT_RELU, "none": ops.ACT_NONE, "leaky": ops.ACT_LEAKY}
         for c in arch.CVN_CONVS:
@@ -323,17 +330,17 @@ class ColorVidNet(nn.Module):
             wp = self._cache.get(c["key"], conv.weight, ops.pack_conv_weight)
             kw = dict(dil=c["dil"], pad=c["dil"], act=act_map[c["act"]], act_slope=0.2)
             pre = c["pre"]
+            src = acts[c["src"]]
             if pre == "norm":
-                kw["in_scale"], kw["in_shift"] = norm_of(c["src"])
+                src = norm_of(c["src"])
             elif pre == "norm_ss":
-                kw["in_scale"], kw["in_shift"] = norm_of(c["src"], c["ss"])
-                kw["in_sub"] = 2
+                src = norm_of(c["src"], c["ss"])
             elif pre == "up":
-                kw["in_scale"], kw["in_shift"] = norm_of(c["src"])
+                src = norm_of(c["src"])
                 kw["in_up"] = 2
             if c["add"] is not None:
                 kw["residual"] = acts[c["add"]]
-            acts[c["dst"]] = ops.conv2d(acts[c["src"]], wp, conv.bias.detach(), **kw)
+            acts[c["dst"]] = ops.conv2d(src, wp, conv.bias.detach(), **kw)
         out = self._mod(arch.CVN_OUT["key"])
         w2 = self._cache.get("conv10_ab", out.weight, lambda w: w.detach().reshape(w.shape[0], -1).contiguous())
         return ops.conv1x1_small(acts["c10_2"], w2, out.bias.detach(), act=ops.ACT_TANH128)

@@ -219,6 +219,23 @@ def affine_act(x, scale, shift, *, residual=None, slope_t=None, up=1, rpad=0, ou
     return out
 
 
+def instnorm_apply(x, *, eps=1e-5, chan_scale=None, residual=None, slope_t=None, up=1, sub=1, rpad=0, out=None,
+                   out_batch_stride=0):
+    """InstanceNorm2d (no affine, biased variance) + optional depthwise scale / skip-add / PReLU / nearest
+    upsample / stride-2 subsample / replicate row pad, in one launch; `out=x` normalises in place."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (chan_scale, "chan_scale"), (residual, "residual"), (slope_t, "slope")):
+        _need(t, nm)
+    N, C, H, W = x.shape
+    VH, VW = ((H + 1) // 2, (W + 1) // 2) if sub == 2 else (H * up, W * up)
+    if out is None:
+        out = torch.empty((N, C, VH + 2 * rpad, VW), device=x.device, dtype=torch.float32)
+    _lib.check(lib.dvc_instnorm_apply(_p(x), _p(residual), _p(slope_t), _p(chan_scale), float(eps), N, C, H, W, up,
+                                      sub, rpad, 0, 0, out_batch_stride, _p(out), None, None, _stream()),
+               "dvc_instnorm_apply")
+    return out
+
+
 def _pool(fn_name, x, k):
     lib = _lib.load()
     _need(x, "x")

@@ -27,7 +27,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 2
+#define DVC_ABI_VERSION 3
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -118,6 +118,19 @@ int dvc_affine_act(const float* x, const float* scale, const float* shift, const
                    const float* slope_ptr, int32_t N, int32_t C, int32_t H, int32_t W, int32_t up,
                    int32_t rpad, int64_t x_batch_stride, int64_t res_batch_stride,
                    int64_t y_batch_stride, float* y, dvcStream stream);
+
+/* InstanceNorm and what follows it in ONE launch: the statistics of every (n,c) plane as dvc_instnorm_stats,
+ * then y = prelu_or_id( x*scale + shift + residual ) as dvc_affine_act, applied by the workgroup that reduced
+ * the plane (its second read hits L2).  sub = 2 keeps every 2nd row/column (the stride-2 depthwise `*_ss`
+ * convs, ColorVidNet.py:12,16,21; chan_scale = their weights); up / rpad as in dvc_affine_act; up and sub
+ * exclude each other.  y is [N][C][VH + 2*rpad][VW], VH = H*up or ceil(H/2); y may be x itself when
+ * up == sub == 1 and rpad == 0.  scale_out / shift_out (both or neither; may be NULL) receive the affine.
+ * The convolution that consumes y then needs no fused input transform and stages through LDS-DMA. */
+int dvc_instnorm_apply(const float* x, const float* residual /* or NULL */, const float* slope_ptr /* or NULL */,
+                       const float* chan_scale /* [C] or NULL */, float eps, int32_t N, int32_t C, int32_t H,
+                       int32_t W, int32_t up, int32_t sub, int32_t rpad, int64_t x_batch_stride,
+                       int64_t res_batch_stride, int64_t y_batch_stride, float* y,
+                       float* scale_out, float* shift_out, dvcStream stream);
 
 /* nn.MaxPool2d(2,2) floor mode, NonlocalNet.py:237-255. planes = N*C. */
 int dvc_maxpool2x2(const float* x, int32_t planes, int32_t H, int32_t W, float* y, dvcStream stream);

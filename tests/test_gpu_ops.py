@@ -200,6 +200,44 @@ def test_instnorm_stats_and_apply(ops):
     assert (big[:, :8] == 0).all() and (big[:, 32:] == 0).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 26, 48), (1, 8, 216, 384), (1, 5, 27, 45), (1, 16, 108, 192)])
+def test_instnorm_apply_fused(ops, shape):
+    """One-launch InstanceNorm + (depthwise scale, stride-2 subsample | skip-add, PReLU | upsample, row pad):
+    same numbers as the reference ops in fp64, and bit-identical to the two-kernel path."""
+    g = torch.Generator().manual_seed(11)
+    N, C, H, W = shape
+    x = (torch.randn(N, C, H, W, generator=g) * 3 + 1.5).cuda()
+    cs = (torch.rand(C, generator=g) + 0.5).cuda()
+    res = torch.randn(N, C, H, W, generator=g).cuda()
+    slope = torch.tensor([0.2], device="cuda")
+    ref = F.instance_norm(x.double().cpu(), eps=1e-5)
+    # plain IN
+    y = ops.instnorm_apply(x)
+    assert (y.double().cpu() - ref).abs().max().item() < 5e-6
+    sc, sh = ops.instnorm_stats(x, 1e-5)
+    assert torch.equal(y, ops.affine_act(x, sc, sh))
+    # IN * depthwise weight, stride 2 (ColorVidNet conv*_norm_ss)
+    y = ops.instnorm_apply(x, chan_scale=cs, sub=2)
+    r = (ref * cs.double().cpu().view(1, C, 1, 1))[:, :, ::2, ::2]
+    assert tuple(y.shape) == tuple(r.shape)
+    assert (y.double().cpu() - r).abs().max().item() < 1e-5
+    # IN + skip + PReLU, in place
+    t = x.clone()
+    y = ops.instnorm_apply(t, residual=res, slope_t=slope, out=t)
+    r = ref + res.double().cpu()
+    r = torch.where(r >= 0, r, r * 0.2)
+    assert y.data_ptr() == t.data_ptr()
+    assert (y.double().cpu() - r).abs().max().item() < 5e-6
+    # IN + PReLU + x2 upsample + replicated rows into a channel slice
+    big = torch.zeros(N, C + 16, 2 * H + 2, 2 * W, device="cuda")
+    ops.instnorm_apply(x, slope_t=slope, up=2, rpad=1, out=big[:, 8:8 + C],
+                       out_batch_stride=(C + 16) * (2 * H + 2) * 2 * W)
+    r = F.interpolate(F.prelu(ref, slope.double().cpu()), scale_factor=2, mode="nearest")
+    r = F.pad(r, (0, 0, 1, 1), "replicate")
+    assert (big[:, 8:8 + C].double().cpu() - r).abs().max().item() < 5e-6
+    assert (big[:, :8] == 0).all() and (big[:, 8 + C:] == 0).all()
+
+
 def test_pools_upsample_l2norm(ops):
     g = torch.Generator().manual_seed(8)
     x = torch.randn(2, 5, 27, 49, generator=g)
