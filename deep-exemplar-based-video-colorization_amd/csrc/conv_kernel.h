@@ -28,6 +28,9 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef CONV_DMA_OCC
+#define CONV_DMA_OCC 3   // workgroups per CU the one-tile-per-wave LDS-DMA variants are register-allocated for
+#endif
 #define CONV_AS1 __attribute__((address_space(1)))
 #define CONV_AS3 __attribute__((address_space(3)))
 
@@ -56,6 +59,9 @@ struct ConvKArgs {
     int split;             // split-K factor S (1 = off): blockIdx.z = n*S + s, raw partial sums go to `part`
     int chunks_per_split;
     float* part;           // [S][N][Cout][OH][OW]
+    long long* dbg_buf;    // timing experiments only: per-workgroup {start, end, HW_ID, XCC_ID} (dvc_debug_conv_trace)
+    int dbg;               // timing experiments only (dvc_debug_conv_variant): 1 = no DMA after the first chunk,
+                           // 2 = no patch DMA, 3 = no weight DMA after the first chunk (results are wrong)
 };
 
 struct ConvCfg {
@@ -86,8 +92,10 @@ __host__ __device__ constexpr int conv_ws_floats(int ck, int kk, int mt) {
 }
 // LDS row pitch: rows of one N-tile must land on disjoint bank ranges for ds_read_b32 (32 banks):
 // pitch == tw (mod 32) for tw in {16, 8}; any pitch >= width for tw == 32.
-__host__ __device__ constexpr int conv_pitch(int tw, int iw_t, int stride) {
-    if (tw == 32 || stride != 1) return iw_t;
+// The LDS-DMA variants take pitch == width instead: a 2-way conflict on the B reads (LDS is ~25 % busy)
+// is cheaper than the 2.7x larger patch, which costs a resident workgroup per CU.
+__host__ __device__ constexpr int conv_pitch(int tw, int iw_t, int stride, bool dma = false) {
+    if (tw == 32 || stride != 1 || dma) return iw_t;
     int p = iw_t;
     while (p % 32 != tw) ++p;
     return p;
@@ -137,7 +145,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 // The LDS patch image is then linear in the staged element index (pitch padding included); cells that
 // read padding zeros are zeroed once and never written again (their lanes are masked off in the DMA).
 template <int WM, int WN, int RM, int RN, int TW, int KS, int DIL, bool GEN, bool DMA = false>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (DMA && RM * RN == 1) ? CONV_DMA_OCC : 2) void conv_mfma_kernel(ConvKArgs a) {
     static_assert(!(GEN && DMA), "LDS-DMA staging needs compile-time geometry");
     constexpr int NT = 64 * WM * WN;
     constexpr int MT = 32 * WM * RM;
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
     // compile-time geometry (ignored by GEN kernels)
     constexpr int C_IH = PH + DIL * (KS - 1);
     constexpr int C_IW = TW + DIL * (KS - 1);
-    constexpr int C_IWP = conv_pitch(TW, C_IW, 1);
+    constexpr int C_IWP = conv_pitch(TW, C_IW, 1, DMA);
     constexpr int EPT = GEN ? CONV_EPT_GEN : DMA ? (CK * C_IH * C_IWP + NT - 1) / NT : (CK * C_IH * C_IW + NT - 1) / NT;
 
     const int stride = GEN ? a.stride : 1;
@@ -186,6 +194,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long* dbgp = nullptr;
+    if (DMA && a.dbg_buf && tid == 0) {
+        dbgp = a.dbg_buf + 4L * (blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z));
+        dbgp[0] = __builtin_amdgcn_s_memtime();
+        dbgp[2] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
+        dbgp[3] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
+    }
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_x = (a.OW + TW - 1) / TW;
@@ -281,17 +296,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
 
     // LDS-DMA staging of chunk `ci` (DMA variants): every lane supplies its own global address, the LDS
     // destination is wave-uniform base + lane * size.
+    const bool dbg_nox = a.dbg == 1 || a.dbg == 2, dbg_now = a.dbg == 1 || a.dbg == 3;
     auto issue_dma = [&](int ci, float* xs, float* ws) {
         const float* xc = xn + (long)ci * CK * HWi;
         const float* wc = a.w + (long)ci * CK * KK * a.Cout;
 #pragma unroll
         for (int t = 0; t < EPT; ++t)
-            if (gofs[t] >= 0)
+            if (gofs[t] >= 0 && !(dbg_nox && ci != c_begin))
                 __builtin_amdgcn_global_load_lds((const CONV_AS1 void*)(xc + (unsigned)gofs[t]),
                                                  (CONV_AS3 void*)(xs + t * NT + wave * 64), 4, 0, 0);
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
-            if (wofs[i] >= 0)
+            if (wofs[i] >= 0 && !(dbg_now && ci != c_begin))
                 __builtin_amdgcn_global_load_lds((const CONV_AS1 void*)(wc + (unsigned)wofs[i]),
                                                  (CONV_AS3 void*)(ws + (i * NT + wave * 64) * 4), 16, 0, 0);
     };
@@ -399,6 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKArgs a)
         if (ci + 1 < nchunks) chunk(ci + 1, xsb1, wsb1, xsb0, wsb0);
     }
 
+    if (dbgp) dbgp[1] = __builtin_amdgcn_s_memtime();
     // ---- epilogue
     if (a.split > 1) {  // split-K: raw partial sums; bias / residual / activation happen in the reduce kernel
         const long OHW = (long)a.OH * a.OW;

@@ -68,6 +68,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
     }
 }
 
+static int g_conv_dbg = 0;
+static long long* g_conv_dbg_buf = nullptr;
+extern "C" void dvc_debug_conv_trace(long long* buf) { g_conv_dbg_buf = buf; }   // not part of the ABI
+extern "C" void dvc_debug_conv_variant(int v) { g_conv_dbg = v; }   // not part of the ABI (timing experiments)
+
 extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_packed,
                           const float* bias, const float* in_scale, const float* in_shift,
                           const float* in_slope_ptr, const float* act_slope_ptr,
@@ -108,6 +113,8 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long)d->Cout * OH * OW;
     a.res_bs = d->res_batch_stride ? d->res_batch_stride : (long)d->Cout * OH * OW;
     a.cin_pad = (d->Cin + 3) & ~3;
+    a.dbg = g_conv_dbg;
+    a.dbg_buf = g_conv_dbg_buf;
 
     const int tw = pick_tw(OW);
     const int rpt = 32 / tw;

@@ -109,6 +109,53 @@ __host__ __device__ __forceinline__ long corr_unit_owner(long u, long U, long G)
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
 
+// ---- the 128-MFMA chain of one key tile, hand-scheduled.
+// The compiler emits `ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs` with a single fragment register pair
+// (no scheduler option or sched_group_barrier pattern made it prefetch), which exposes the LDS latency
+// 64 times per tile.  Here the A fragments run two MFMA pairs ahead in two register pairs (a0,a1 / b0,b1):
+//   wait(pair p landed) ; 2 MFMAs on pair p ; issue the reads of pair p+2 into the same registers.
+// LDS returns in order, so `s_waitcnt lgkmcnt(2)` (the two reads of the younger pair may be outstanding)
+// is exact.  One asm statement covers 16 MFMAs (operand limit); fragment s lives at byte offset s*256.
+#define CORR_STR2(x) #x
+#define CORR_STR(x) CORR_STR2(x)
+#define CORR_RD(r0, r1, s)                                                      \
+    "ds_read_b32 %[" #r0 "], %[addr] offset:(" CORR_STR(s) ")*256\n\t"          \
+    "ds_read_b32 %[" #r1 "], %[addr] offset:((" CORR_STR(s) ")+1)*256\n\t"
+#define CORR_MM(r0, r1, q0, q1)                                                 \
+    "v_mfma_f32_32x32x2_f32 %[acc], %[" #r0 "], %[" #q0 "], %[acc]\n\t"         \
+    "v_mfma_f32_32x32x2_f32 %[acc], %[" #r1 "], %[" #q1 "], %[acc]\n\t"
+#define CORR_W2 "s_waitcnt lgkmcnt(2)\n\t"
+#define CORR_W0 "s_waitcnt lgkmcnt(0)\n\t"
+#define CORR_CHAIN_OPS(B)                                                                                   \
+    : [acc] "+v"(acc), [a0] "+v"(fa0), [a1] "+v"(fa1), [b0] "+v"(fb0), [b1] "+v"(fb1)                      \
+    : [addr] "v"(kaddr), [q0] "v"(qreg[(B) * 16 + 0]), [q1] "v"(qreg[(B) * 16 + 1]),                       \
+      [q2] "v"(qreg[(B) * 16 + 2]), [q3] "v"(qreg[(B) * 16 + 3]), [q4] "v"(qreg[(B) * 16 + 4]),            \
+      [q5] "v"(qreg[(B) * 16 + 5]), [q6] "v"(qreg[(B) * 16 + 6]), [q7] "v"(qreg[(B) * 16 + 7]),            \
+      [q8] "v"(qreg[(B) * 16 + 8]), [q9] "v"(qreg[(B) * 16 + 9]), [q10] "v"(qreg[(B) * 16 + 10]),          \
+      [q11] "v"(qreg[(B) * 16 + 11]), [q12] "v"(qreg[(B) * 16 + 12]), [q13] "v"(qreg[(B) * 16 + 13]),      \
+      [q14] "v"(qreg[(B) * 16 + 14]), [q15] "v"(qreg[(B) * 16 + 15])                                       \
+    : "memory"
+// blocks 0..6: every pair refills its registers with the pair four fragments later
+#define CORR_CHAIN_BLOCK(B)                                                                                 \
+    asm volatile(CORR_W2 CORR_MM(a0, a1, q0, q1) CORR_RD(a0, a1, (B) * 16 + 4)                              \
+                 CORR_W2 CORR_MM(b0, b1, q2, q3) CORR_RD(b0, b1, (B) * 16 + 6)                              \
+                 CORR_W2 CORR_MM(a0, a1, q4, q5) CORR_RD(a0, a1, (B) * 16 + 8)                              \
+                 CORR_W2 CORR_MM(b0, b1, q6, q7) CORR_RD(b0, b1, (B) * 16 + 10)                             \
+                 CORR_W2 CORR_MM(a0, a1, q8, q9) CORR_RD(a0, a1, (B) * 16 + 12)                             \
+                 CORR_W2 CORR_MM(b0, b1, q10, q11) CORR_RD(b0, b1, (B) * 16 + 14)                           \
+                 CORR_W2 CORR_MM(a0, a1, q12, q13) CORR_RD(a0, a1, (B) * 16 + 16)                           \
+                 CORR_W2 CORR_MM(b0, b1, q14, q15) CORR_RD(b0, b1, (B) * 16 + 18) CORR_CHAIN_OPS(B))
+// block 7: no reads past fragment 127; ends with the wait states an MFMA result needs before a VALU read
+#define CORR_CHAIN_LAST()                                                                                   \
+    asm volatile(CORR_W2 CORR_MM(a0, a1, q0, q1) CORR_RD(a0, a1, 7 * 16 + 4)                                \
+                 CORR_W2 CORR_MM(b0, b1, q2, q3) CORR_RD(b0, b1, 7 * 16 + 6)                                \
+                 CORR_W2 CORR_MM(a0, a1, q4, q5) CORR_RD(a0, a1, 7 * 16 + 8)                                \
+                 CORR_W2 CORR_MM(b0, b1, q6, q7) CORR_RD(b0, b1, 7 * 16 + 10)                               \
+                 CORR_W2 CORR_MM(a0, a1, q8, q9) CORR_RD(a0, a1, 7 * 16 + 12)                               \
+                 CORR_W2 CORR_MM(b0, b1, q10, q11) CORR_RD(b0, b1, 7 * 16 + 14)                             \
+                 CORR_W2 CORR_MM(a0, a1, q12, q13)                                                          \
+                 CORR_W0 CORR_MM(b0, b1, q14, q15) "s_nop 15\n\ts_nop 7\n\t" CORR_CHAIN_OPS(7))
+
 template <bool WTA, bool VEC4>
 __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     // two key tiles (double buffer, 2 x 32 KB) + three pooled-Lab tiles [3][256] (first 96 floats used).
@@ -117,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[2 * CORR_C * CORR_KT + 3 * 256];
     float* bl = smem + 2 * CORR_C * CORR_KT;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int P = a.P;
     const long G = gridDim.x;
@@ -171,18 +218,29 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     // Everything in the steady-state loop is branch-free (one basic block) so that the scheduler can
     // interleave the matrix and vector streams.
     float blr = 0.f;
+    unsigned dma_ofs[8];  // element offset of this lane's 16-byte piece of chunk i (row 8c + lane/8, col 4*(lane%8))
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_ofs[i] = (unsigned)(((i * 4 + wave) * 8 + (lane >> 3)) * P + (lane & 7) * 4);
     float kr[VEC4 ? 1 : (CORR_C * CORR_KT) / 256];
     const int blc = tid < 3 * CORR_KT ? (tid >> 5) : 0, blj = tid & 31;
     auto issue = [&](int t, int buf) {
         const int k0 = t * CORR_KT;
         if (VEC4) {
             float* kb = smem + buf * CORR_C * CORR_KT;
+            if (k0 + CORR_KT <= P) {  // full tile: scalar base + loop-invariant lane offset, no address VALU
+                const float* src = ph + k0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = i * 4 + wave;  // 1 KB chunk = rows 8c .. 8c+7
-                const int row = c * 8 + (lane >> 3), col = (lane & 7) * 4;
-                const float* src = ph + (unsigned)(row * P + (k0 + col < P ? k0 + col : 0));
-                __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(kb + c * 256), 16, 0, 0);
+                for (int i = 0; i < 8; ++i)
+                    __builtin_amdgcn_global_load_lds((const AS1 void*)(src + dma_ofs[i]),
+                                                     (AS3 void*)(kb + (i * 4 + wave) * 256), 16, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = i * 4 + wave;  // 1 KB chunk = rows 8c .. 8c+7
+                    const int row = c * 8 + (lane >> 3), col = (lane & 7) * 4;
+                    const float* src = ph + (unsigned)(row * P + (k0 + col < P ? k0 + col : 0));
+                    __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(kb + c * 256), 16, 0, 0);
+                }
             }
         } else {
 #pragma unroll
@@ -203,46 +261,56 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         bl[lbuf * 256 + tid] = blr;
     };
 
-    // ---- online softmax of the PENDING (previous) tile, run between the MFMA segments of the current one.
-    // ATen computes s = fl32(f / T) (true division) and p = exp(s - max s).  The IEEE division and the
-    // precise expf cost ~25 VALU instructions per affinity, and they are NOT free next to the matrix pipe
-    // when two waves share a SIMD (measured: +37 us per launch).  At T = 1e-10 all but one affinity per row
-    // give p == 0 exactly, so every step is guarded by a cheap WAVE-UNIFORM test and the exact arithmetic
-    // only runs when some lane can actually contribute:
-    //   * mf  = running maximum in the affinity domain (exact), m = fl32(mf / T) its image;
-    //   * an affinity f can have p != 0 only if fl32(f/T) - m > -104; (f - mf) * invT approximates that
-    //     difference to within a few ulp(m), which `slack` covers (ulp(m) ~ 1e3 at T = 1e-10).
-    float pv[16];            // pending tile's affinities after WTA / masking (-inf = masked key)
-    float tmax_pend = -INFINITY;
-    float mf = -INFINITY;    // running max affinity (after WTA), exact
-    float slack = 120.f;
-    const float* blp = bl;   // pooled-Lab tile of the pending tile
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pv[r] = -INFINITY;
-
-    // (1) right after a tile's MFMA chain: row max / argmax bookkeeping, WTA, masking
-    auto finish_tile = [&](const f32x16& sacc, int k0) {
-        float tilemax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float f = sacc[r];
-            const bool kvalid = key < P;
-            const bool better = kvalid & (f > fmax);  // strict '>' keeps the lowest index on ties
-            fmax = better ? f : fmax;
-            amax = better ? key : amax;
-            if (WTA) f = (f == fq) ? f : f * a.wta_scale;
-            f = kvalid ? f : -INFINITY;
-            pv[r] = f;
-            tilemax = fmaxf(tilemax, f);
-        }
-        tmax_pend = tilemax;
+    // ---- online softmax, run on a tile's accumulators right after its MFMA chain.
+    // The fp32 MFMA and ordinary fp32 VALU work share the SIMD's fp32 lanes (the vector and matrix fp32
+    // peaks are the same number), so softmax instructions can not be hidden under the chain; what can be
+    // hidden is latency, and that is the job of the OTHER wave on the SIMD (2 workgroups per CU).  The
+    // chain is therefore one straight block of 128 MFMAs, and the softmax a separate block whose cost is
+    // kept low by guarding every step with a cheap WAVE-UNIFORM test:
+    //   * mf = running maximum in the affinity domain (exact), m = fl32(mf / T) its image (ATen computes
+    //     s = fl32(f / T) with a true division and p = exp(s - max s));
+    //   * an affinity can have p != 0 only if s - m > -104, which implies f >= thr := mf - (120 T +
+    //     4.8e-7 |mf|) (the second term covers the two roundings of s and m); at T = 1e-10 that is ~8 ulp
+    //     below the maximum, so all but the row maxima themselves skip the arithmetic;
+    //   * the row arg-max (lowest index on ties) is tracked in the same guarded step: the row maximum
+    //     always passes the guard.
+    // fl32(f / T) for the fixed divisor T: q0 = f*y, two residual corrections with fma (y = fl32(1/T));
+    // correctly rounded (Markstein), checked against true division in tests/test_gpu_ops.py.
+    float mf = -INFINITY;    // running max affinity (after WTA / masking), exact
+    float thr = -INFINITY;
+    const float Tn = -a.T, ry = a.invT;
+    auto div_T = [&](float f) {
+        float q = f * ry;
+        q = fmaf(fmaf(Tn, q, f), ry, q);
+        q = fmaf(fmaf(Tn, q, f), ry, q);
+        return q;
     };
-    // (2) the pending tile raises some lane's running max: new m = fl32(mf/T), rescale the running sums
-    auto rescale = [&]() {
-        if (__any(tmax_pend > mf)) {
-            const float mf_new = fmaxf(mf, tmax_pend);
-            const float m_new = mf_new / a.T;                      // true division, as ATen's f / T
+    auto process_tile = [&](f32x16& sacc, int k0, const float* blp) {
+        // (1) WTA / partial last tile only: raw max bookkeeping, then rewrite the affinities in place
+        if (WTA || k0 + CORR_KT > P) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float f = sacc[r];
+                const bool kvalid = key < P;
+                const bool better = kvalid & (f > fmax);  // strict '>' keeps the lowest index on ties
+                fmax = better ? f : fmax;
+                amax = better ? key : amax;
+                if (WTA) f = (f == fq) ? f : f * a.wta_scale;
+                sacc[r] = kvalid ? f : -INFINITY;
+            }
+        }
+        // (2) tile maximum (v_max3)
+        float t0m = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+        float t1m = fmaxf(fmaxf(sacc[3], sacc[4]), sacc[5]);
+        float t2m = fmaxf(fmaxf(sacc[6], sacc[7]), sacc[8]);
+        float t3m = fmaxf(fmaxf(sacc[9], sacc[10]), sacc[11]);
+        float t4m = fmaxf(fmaxf(sacc[12], sacc[13]), sacc[14]);
+        const float tmax = fmaxf(fmaxf(fmaxf(t0m, t1m), fmaxf(t2m, t3m)), fmaxf(t4m, sacc[15]));
+        // (3) the tile raises some lane's running max: new image m, rescale the running sums, new guard
+        if (__any(tmax > mf)) {
+            const float mf_new = fmaxf(mf, tmax);
+            const float m_new = (mf_new == -INFINITY) ? -INFINITY : div_T(mf_new);   // (all keys masked so far)
             const float sc = (mf == -INFINITY) ? 0.f : __expf(m - m_new);
             l *= sc;
             y0 *= sc;
@@ -250,22 +318,28 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
             y2 *= sc;
             mf = mf_new;
             m = m_new;
-            slack = 120.f + fabsf(m) * 4.8e-7f;
+            thr = mf_new - fmaf(4.8e-7f, fabsf(mf_new), 120.f * a.T);
         }
-    };
-    // (3) one pending affinity: p = exp(fl32(f/T) - m) if it can be non-zero for any lane of the wave.
-    // __expf (hardware exp2, rel. error ~2e-6 for |x| < 100) is exact in the two cases that decide the
-    // T -> 0 regime; at soft temperatures its error is far below the fp32 noise of the affinities / T.
-    auto element = [&](int r) {
-        const float f = pv[r];
-        const bool cand = (f - mf) * a.invT > -slack;              // masked keys: -inf -> false
-        if (__any(cand)) {
-            const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float pe = cand ? __expf(f / a.T - m) : 0.f;   // v_exp_f32: exp(0) == 1 and exp(-big) == 0 exactly
-            l += pe;
-            y0 = fmaf(pe, blp[kl], y0);
-            y1 = fmaf(pe, blp[CORR_KT + kl], y1);
-            y2 = fmaf(pe, blp[2 * CORR_KT + kl], y2);
+        // (4) affinities that can contribute (or be the arg-max).  __expf (hardware exp2, rel. error ~2e-6
+        // for |x| < 100) gives exp(0) == 1 and exp(-big) == 0 exactly — the two cases that decide the
+        // T -> 0 regime; at soft temperatures its error is far below the fp32 noise of the affinities / T.
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float f = sacc[r];
+            const bool cand = f >= thr;   // masked keys are -inf; thr is -inf only while mf is
+            if (__any(cand)) {
+                const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float pe = (cand && f > -INFINITY) ? __expf(div_T(f) - m) : 0.f;
+                l += pe;
+                y0 = fmaf(pe, blp[kl], y0);
+                y1 = fmaf(pe, blp[CORR_KT + kl], y1);
+                y2 = fmaf(pe, blp[2 * CORR_KT + kl], y2);
+                if (!WTA) {
+                    const bool better = f > fmax;
+                    fmax = better ? f : fmax;
+                    amax = better ? k0 + kl : amax;
+                }
+            }
         }
     };
 
@@ -283,47 +357,34 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 0] = __builtin_amdgcn_s_memtime();
         issue(min(t + 1, t1 - 1), cur ^ 1);  // (the last iteration re-stages its own tile: harmless)
 
-        // S^T tile of THIS key tile: 128 dependent MFMAs (K = 256) in 16 segments of 8.  The softmax of
-        // the PREVIOUS tile is spliced in, one affinity per segment.  An in-order wave overlaps VALU with
-        // an MFMA only if the VALU sits between that MFMA and the next (dependent) one, so each segment
-        // is pinned with sched_barrier and interleaved 1 MFMA : 1 LDS read : ~10 VALU inside.
+        // S^T tile of THIS key tile: 128 dependent MFMAs (K = 256), one basic block; the A fragments are
+        // conflict-free ds_reads the scheduler is free to hoist
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* kp = smem + cur * CORR_C * CORR_KT + hi * CORR_KT + l31;
-        asm volatile("" : "+v"(acc), "+v"(l), "+v"(y0), "+v"(y1), "+v"(y2));
-#pragma unroll
-        for (int seg = 0; seg < 16; ++seg) {
-#pragma unroll
-            for (int s = seg * 8; s < seg * 8 + 8; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s * CORR_KT], qreg[s], acc, 0, 0, 0);
-            if (!a.dbg_variant) {
-                if (seg == 0) rescale();
-                element(seg);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // VALU
-            }
-            // data fence: ties the matrix stream (acc) and the vector stream (l, y*) to this point so
-            // that neither can be hoisted / sunk out of its segment by earlier passes
-            asm volatile("" : "+v"(acc), "+v"(l), "+v"(y0), "+v"(y1), "+v"(y2));
-        }
+        // LDS byte address of this lane's fragment 0: A[i = l31][k = hi] of the tile in buffer `cur`
+        const unsigned kaddr = (unsigned)(size_t)(AS3 float*)(smem + cur * CORR_C * CORR_KT + hi * CORR_KT + l31);
+        float fa0, fa1, fb0, fb1;
+        asm volatile(CORR_RD(a0, a1, 0) CORR_RD(b0, b1, 2)
+                     : [a0] "=&v"(fa0), [a1] "=&v"(fa1), [b0] "=&v"(fb0), [b1] "=&v"(fb1)
+                     : [addr] "v"(kaddr)
+                     : "memory");
+        CORR_CHAIN_BLOCK(0);
+        CORR_CHAIN_BLOCK(1);
+        CORR_CHAIN_BLOCK(2);
+        CORR_CHAIN_BLOCK(3);
+        CORR_CHAIN_BLOCK(4);
+        CORR_CHAIN_BLOCK(5);
+        CORR_CHAIN_BLOCK(6);
+        CORR_CHAIN_LAST();
         if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 1] = __builtin_amdgcn_s_memtime();
-        finish_tile(acc, t * CORR_KT);
+        if (!a.dbg_variant) process_tile(acc, t * CORR_KT, bl + ((t - t0) % 3) * 256);
         if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 2] = __builtin_amdgcn_s_memtime();
-        blp = bl + ((t - t0) % 3) * 256;
         commit(cur ^ 1, (t + 1 - t0) % 3);
         __syncthreads();  // next tile landed (DMA drained / stores visible); this tile's reads done
         if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 3] = __builtin_amdgcn_s_memtime();
     }
     if (dbgh) dbgh[2] = __builtin_amdgcn_s_memtime();
-    // drain: softmax of the last tile
-    rescale();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) element(r);
 
     // ---- write this lane's partial state: slot = split*2 + hi
     if (qvalid) {
