@@ -66,6 +66,9 @@ class ClipColorizer:
         self.IB_lab = None
         self.features_B = None
         self.ex_cache = None
+        self.last_lab = None         # [L, ab] of the last frame colourised by clip()
+        self._side_streams = []
+        self._main_stream = None
 
     def set_exemplar(self, IB_lab):
         """test.py:61-66: Lab -> RGB -> VGG features of the reference image."""
@@ -93,14 +96,71 @@ class ClipColorizer:
                                        temperature=self.temperature, exemplar_cache=self.ex_cache)
         return ab, nl
 
-    def clip(self, frames_lab, frame_propagate=False):
-        """Recurrence of test.py:68-96; returns the list of ab predictions."""
-        last = None
+    def clip(self, frames_lab, frame_propagate=False, last=None, lookahead=2):
+        """Recurrence of test.py:68-96; returns the list of ab predictions.
+
+        Only ColorVidNet(t) consumes frame t-1's prediction (test.py:96 -> FrameColor.py:63-64); the
+        front end of a frame (VGG19 + WarpNet + correlation) depends on nothing but the frame and the
+        exemplar.  With `lookahead` > 0 the front ends of the next `lookahead` frames run on side HIP
+        streams while the current stream runs the ColorVidNet chain, so their workgroups fill the CUs
+        the other stream's layer leaves idle (few-tile layers, tail rounds).  Same kernels, same
+        per-frame arithmetic and order: the predictions are bit-identical to the sequential loop.
+        `last` (optional) continues the recurrence from an earlier call."""
+        frames_lab = list(frames_lab)
+        if not frames_lab:
+            return []
+        if last is None:
+            last = self.IB_lab if frame_propagate else torch.zeros_like(frames_lab[0])
         outs = []
-        for IA_lab in frames_lab:
-            if last is None:
-                last = self.IB_lab if frame_propagate else torch.zeros_like(IA_lab)
-            ab, _ = self.frame(IA_lab, last)
-            last = torch.cat((IA_lab[:, 0:1], ab), dim=1)   # test.py:96 (pure data movement)
+        if lookahead <= 0 or len(frames_lab) < 2:
+            for IA_lab in frames_lab:
+                ab, _ = self.frame(IA_lab, last)
+                last = torch.cat((IA_lab[:, 0:1], ab), dim=1)   # test.py:96 (pure data movement)
+                outs.append(ab)
+            self.last_lab = last
+            return outs
+        caller = torch.cuda.current_stream()
+        lo_prio, hi_prio = torch.cuda.Stream.priority_range()
+        if self._main_stream is None:
+            # the ColorVidNet recurrence is the critical path: highest priority; the front ends fill in
+            self._main_stream = torch.cuda.Stream(priority=hi_prio)
+        if len(self._side_streams) < lookahead:
+            self._side_streams += [torch.cuda.Stream(priority=lo_prio)
+                                   for _ in range(lookahead - len(self._side_streams))]
+        cur = self._main_stream
+        side = self._side_streams[:lookahead]
+        for s in side + [cur]:
+            s.wait_stream(caller)       # inputs, weights and the exemplar cache were produced on the caller's stream
+        fronts = {}
+
+        def launch_front(t):
+            s = side[t % lookahead]
+            with torch.cuda.stream(s):
+                IA_lab = frames_lab[t].detach().contiguous().float()
+                warped, sim, _ = warp_color(IA_lab[:, 0:1], self.IB_lab, self.features_B, self.vgg, self.warp,
+                                            self.col, 0, temperature=self.temperature,
+                                            exemplar_cache=self.ex_cache)
+                ev = torch.cuda.Event()
+                ev.record(s)
+            fronts[t] = (IA_lab, warped, sim, ev)
+
+        T = len(frames_lab)
+        for t in range(min(lookahead, T)):
+            launch_front(t)
+        for t in range(T):
+            IA_lab, warped, sim, ev = fronts.pop(t)
+            cur.wait_event(ev)
+            for x in (IA_lab, warped, sim):
+                x.record_stream(cur)    # allocated on a side stream, consumed here
+            with torch.cuda.stream(cur):
+                color_input = ops.pack_color_input(IA_lab, warped, sim, last.detach().contiguous().float())
+                ab = self.col(color_input)
+                last = torch.cat((IA_lab[:, 0:1], ab), dim=1)
             outs.append(ab)
+            if t + lookahead < T:       # (issued after the critical-path launches of frame t)
+                launch_front(t + lookahead)
+        caller.wait_stream(cur)
+        for x in outs + [last]:
+            x.record_stream(caller)     # allocated on the recurrence stream, handed to the caller's stream
+        self.last_lab = last
         return outs

@@ -472,3 +472,37 @@ def test_full_res_432x768_properties(nets):
     idx = torch.randint(0, P, (64,), generator=g)
     f = th[0, :, idx.cuda()].double().t() @ ph[0].double()
     assert (f.max(1)[0].float() - o1["sim_small"].view(-1)[idx.cuda()]).abs().max().item() < 2e-6
+
+
+@pytest.mark.gpu
+def test_clip_pipelined_equals_sequential():
+    """ClipColorizer.clip with look-ahead (front ends on side HIP streams) is bit-identical to the per-frame
+    recurrence of test.py:68-96, for every look-ahead depth, and continues a recurrence via `last`."""
+    import contextlib
+    import io
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    from models.ColorVidNet import ColorVidNet
+    from models.NonlocalNet import VGG19_pytorch, WarpNet
+    dev = torch.device("cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        nets = (VGG19_pytorch(), WarpNet(1), ColorVidNet(7))
+    for m, sd in zip(nets, (synth.vgg19_state_dict(0), synth.warpnet_state_dict(0), synth.colorvidnet_state_dict(0))):
+        m.load_state_dict(sd)
+        m.eval().to(dev)
+    H, W = 48, 80
+    frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W).to(dev) for i in range(7)]
+    cc = ClipColorizer(*nets, temperature=1e-10)
+    cc.set_exemplar(synth.synth_lab(synth.EXEMPLAR_SEED, H, W).to(dev))
+    ref = cc.clip(frames, lookahead=0)
+    for la in (1, 2, 3):
+        got = cc.clip(frames, lookahead=la)
+        torch.cuda.synchronize()
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), la
+    # split the clip in two calls
+    first = cc.clip(frames[:3], lookahead=2)
+    rest = cc.clip(frames[3:], last=cc.last_lab, lookahead=2)
+    for a, b in zip(first + rest, ref):
+        assert torch.equal(a, b)
