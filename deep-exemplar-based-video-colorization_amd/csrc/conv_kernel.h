@@ -28,6 +28,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// (4 for cfg 3, which would fit LDS-wise, was measured: no gain, 128-VGPR cap costs spills)
 #ifndef CONV_DMA_OCC
 #define CONV_DMA_OCC 3   // workgroups per CU the one-tile-per-wave LDS-DMA variants are register-allocated for
 #endif

@@ -140,6 +140,12 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
         cfg -= 16;
         allow_dma = false;
     }
+    if (cfg < 0 && allow_dma && !gen && !in_scale && !d->in_prelu && d->Cin % conv_ck(d->ksize, 1, false) == 0 &&
+        d->Cout % 32 == 0) {
+        // LDS-DMA layers (profiles/r01_conv_layer_sweep.json): the one-tile-per-wave configurations win on
+        // every shape of the network (3 resident workgroups per CU), the 64-channel one when Cout allows it
+        cfg = d->Cout % 64 == 0 ? 4 : 3;
+    }
     if (cfg < 0) {
         // Cost model fitted to the per-layer sweep (profiles/r01_conv_layer_sweep.json): a layer takes
         // (32x32 MFMA tiles per wave, padding included) x (waves per SIMD, at least one round) x a
