@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     float mf = -INFINITY;    // running max affinity (after WTA / masking), exact
     float thr = -INFINITY;
     const float Tn = -a.T, ry = a.invT;
+    const bool sharp = 120.f * a.T < 1e-6f;   // wave-uniform: which organisation of step (4) pays
     auto div_T = [&](float f) {
         float q = f * ry;
         q = fmaf(fmaf(Tn, q, f), ry, q);
@@ -308,7 +309,9 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         float t4m = fmaxf(fmaxf(sacc[12], sacc[13]), sacc[14]);
         const float tmax = fmaxf(fmaxf(fmaxf(t0m, t1m), fmaxf(t2m, t3m)), fmaxf(t4m, sacc[15]));
         // (3) the tile raises some lane's running max: new image m, rescale the running sums, new guard
-        if (__any(tmax > mf)) {
+        // (lanes of queries beyond P hold all-zero fragments: every affinity ties at 0 — keep them out of the
+        // wave-uniform tests, their state is never stored)
+        if (__any(qvalid & (tmax > mf))) {
             const float mf_new = fmaxf(mf, tmax);
             const float m_new = (mf_new == -INFINITY) ? -INFINITY : div_T(mf_new);   // (all keys masked so far)
             const float sc = (mf == -INFINITY) ? 0.f : __expf(m - m_new);
@@ -323,10 +326,41 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         // (4) affinities that can contribute (or be the arg-max).  __expf (hardware exp2, rel. error ~2e-6
         // for |x| < 100) gives exp(0) == 1 and exp(-big) == 0 exactly — the two cases that decide the
         // T -> 0 regime; at soft temperatures its error is far below the fp32 noise of the affinities / T.
+        // (4a) sharp temperatures (guard window below ~1e-6): a lane almost never has more than ONE
+        // affinity above the guard in a tile, and that one is its tile maximum.  Count and locate them
+        // (3 VALU per affinity, no branches); unless some lane has two, a single update per TILE replaces
+        // the per-affinity steps of (4b) — the terms it skips are exact zeros, so the sums are bit-identical.
+        if (sharp) {
+            int cnt = 0, idx = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool c = qvalid & (sacc[r] >= thr);
+                cnt += c ? 1 : 0;
+                idx = c ? r : idx;
+            }
+            if (!__any(cnt > 1)) {
+                if (__any(cnt == 1)) {
+                    const bool has = cnt == 1;   // (tmax is then finite: a masked -inf never passes a finite guard)
+                    const int kl = (idx & 3) + 8 * (idx >> 2) + 4 * hi;
+                    const float pe = has ? __expf(div_T(tmax) - m) : 0.f;
+                    l += pe;
+                    y0 = fmaf(pe, blp[kl], y0);
+                    y1 = fmaf(pe, blp[CORR_KT + kl], y1);
+                    y2 = fmaf(pe, blp[2 * CORR_KT + kl], y2);
+                    if (!WTA) {
+                        const bool better = has & (tmax > fmax);
+                        fmax = better ? tmax : fmax;
+                        amax = better ? k0 + kl : amax;
+                    }
+                }
+                return;
+            }
+        }
+        // (4b) general case
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float f = sacc[r];
-            const bool cand = f >= thr;   // masked keys are -inf; thr is -inf only while mf is
+            const bool cand = qvalid & (f >= thr);   // masked keys are -inf; thr is -inf only while mf is
             if (__any(cand)) {
                 const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const float pe = (cand && f > -INFINITY) ? __expf(div_T(f) - m) : 0.f;
