@@ -101,3 +101,49 @@ def test_product_code_never_imports_oracle():
                 for ln in open(os.path.join(dp, f)).read().splitlines():
                     assert not re.match(r"\s*(from|import)\s+oracle", ln), (f, ln)
                     assert "dvc_oracle" not in ln, (f, ln)
+
+
+def test_fma_division_by_constant_is_correctly_rounded():
+    """csrc/corr.hip computes ATen's s = fl32(f / T) for the fixed divisor T as q = f*y followed by two fma
+    residual corrections (y = fl32(1/T)).  Check the recipe against exact rational arithmetic: it must
+    give the correctly rounded quotient, otherwise ties at T = 1e-10 would differ from the reference."""
+    import math
+    from fractions import Fraction
+
+    import numpy as np
+
+    def rn32(x):
+        """Round a Fraction to the nearest float32 (ties to even); returns a python float."""
+        if x == 0:
+            return 0.0
+        sign = -1 if x < 0 else 1
+        x = abs(x)
+        e = math.floor(math.log2(x.numerator) - math.log2(x.denominator))
+        while Fraction(2) ** e > x:
+            e -= 1
+        while Fraction(2) ** (e + 1) <= x:
+            e += 1
+        e = max(e, -126)
+        ulp = Fraction(2) ** (e - 23)
+        q = x / ulp
+        n = q.numerator // q.denominator
+        rem = q - n
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and n % 2 == 1):
+            n += 1
+        return float(sign * n * ulp)
+
+    def fma(a, b, c):
+        return rn32(Fraction(a) * Fraction(b) + Fraction(c))
+
+    rng = np.random.default_rng(0)
+    for T in (1e-10, 0.01, 0.005, 1.0, 3.3e-7, 1e-4, 0.7):
+        T = float(np.float32(T))
+        y = rn32(Fraction(1) / Fraction(T))
+        fs = np.concatenate([rng.uniform(-1, 1, 700), rng.uniform(0.2, 0.3, 300), rng.uniform(-1e-3, 1e-3, 100),
+                             [1.0, -1.0, 0.0, 0.5, 2.0 ** -20, 1 - 2.0 ** -24]]).astype(np.float32)
+        for f in fs:
+            f = float(f)
+            q = rn32(Fraction(f) * Fraction(y))
+            q = fma(fma(-T, q, f), y, q)
+            q = fma(fma(-T, q, f), y, q)
+            assert q == rn32(Fraction(f) / Fraction(T)), (T, f)
