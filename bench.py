@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hw", default="216x384",
+                    help="frame size HxW; the default is BASELINE configs[1] (the metric's configuration), "
+                         "432x768 is configs[3] (information only: no CPU baseline, traffic not re-measured)")
     ap.add_argument("--lookahead", type=int, default=2,
                     help="frames whose front end runs ahead on side HIP streams (0 = per-frame calls on one stream)")
     ap.add_argument("--no-autotune", action="store_true", help="use the static tile cost model instead of first-use timing")
@@ -119,6 +122,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    global H, W, P, CORR_FLOPS, CORR_BYTES, PATH_FLOPS, CORR_TRAFFIC_BYTES
+    if args.hw != "216x384":
+        H, W = (int(v) for v in args.hw.lower().split("x"))
+        assert H % 16 == 0 and W % 16 == 0, "--hw: multiples of 16"
+        scale = (H * W) / (216.0 * 384.0)
+        P = (H // 4) * (W // 4)
+        CORR_FLOPS = 2.0 * P * P * C + 2.0 * P * P * 3
+        CORR_BYTES = 4.0 * (2 * P * C + 3 * P + 3 * P + P)
+        PATH_FLOPS = (348.4e9 - 13.92e9) * scale + CORR_FLOPS     # convolutions scale with the pixels
+        CORR_TRAFFIC_BYTES = None
+        args.no_cpu_baseline = True
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if use_dist:
@@ -244,11 +258,12 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "colorized frames/sec/GPU at 216x384; correlation HBM GB/s vs roofline",
+            "metric": f"colorized frames/sec/GPU at {H}x{W}; correlation HBM GB/s vs roofline",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": n_gpus, "steps": K, "warmup": Wm,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 1x3x216x384 frame + one exemplar per step, HIP "
+            "config": {"workload": ("BASELINE configs[1]: 1x3x216x384" if (H, W) == (216, 384) else f"1x3x{H}x{W}") +
+                                   " frame + one exemplar per step, HIP "
                                    "VGG19 + WarpNet/fused correlation + ColorVidNet forward, fp32, clip "
                                    "recurrence as test.py:68-96",
                        "H": H, "W": W, "temperature": 1e-10, "weights": "synthetic seed 0",
