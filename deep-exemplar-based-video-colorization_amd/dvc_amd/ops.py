@@ -149,6 +149,9 @@ if _autotune:
     _load_tuned()  # env-enabled autotune: pick up a persisted table
 
 
+_TUNE_SPLITS = tuple(int(v) for v in _os.environ.get("DVC_TUNE_SPLITS", "1,2,3,4,6,8").split(","))
+
+
 def _tune_conv(lib, d, tensors):
     """Time every (cfg, split_k) candidate for descriptor `d`; returns the fastest pair."""
     x, w_packed, bias, in_scale, in_shift, in_slope_t, act_slope_t, residual, out = tensors
@@ -165,7 +168,7 @@ def _tune_conv(lib, d, tensors):
     # (layers without a fused input transform stage through LDS-DMA; forcing register staging, cfg 16 + k,
     # never won in the per-layer sweep, so it is not a candidate)
     for cfg in (0, 1, 2, 3, 4):
-        for sk in (1, 2, 3, 4, 6, 8):
+        for sk in _TUNE_SPLITS:
             d.cfg, d.split_k = cfg, sk
             if launch() != 0:          # configuration does not fit this geometry
                 break

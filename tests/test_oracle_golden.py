@@ -26,6 +26,8 @@ def test_golden_files_present(golden_dir):
 def test_oracle_matches_reference_golden(golden_dir, weights, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     H, W, nf, T = int(g["H"]), int(g["W"]), int(g["n_frames"]), float(g["temperature"])
+    # replay with the thread count the fixture was recorded with (ATen CPU results depend on it)
+    torch.set_num_threads(int(g["num_threads"]) if "num_threads" in g.files else 8)
     sd_v, sd_w, sd_c = weights
     IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
     with torch.no_grad():
