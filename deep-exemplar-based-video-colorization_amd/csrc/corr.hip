@@ -193,18 +193,8 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     const float* ph = a.phi + (long)b * CORR_C * P;
     const float* blb = a.blab + (long)b * 3 * P;
 
-    // query fragment: B[k = 2s+hi][j = l31] for s = 0..127
-    // (unconditional loads from a clamped position, then masked: 128 independent loads in flight)
+    // query fragment: B[k = 2s+hi][j = l31] for s = 0..127 (loaded below, after the first key tile's DMA)
     float qreg[CORR_C / 2];
-    {
-        const float* tq = th + (unsigned)(hi * P + (qvalid ? query : 0));
-#pragma unroll
-        for (int s = 0; s < CORR_C / 2; ++s) qreg[s] = tq[(unsigned)(2 * s * P)];
-        if (!qvalid) {
-#pragma unroll
-            for (int s = 0; s < CORR_C / 2; ++s) qreg[s] = 0.f;
-        }
-    }
 
     float m = -INFINITY, l = 0.f, y0 = 0.f, y1 = 0.f, y2 = 0.f, fmax = -INFINITY;
     int amax = 0;
@@ -377,11 +367,21 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         }
     };
 
-    if (t0 < t1) {
-        issue(t0, 0);
-        commit(0, 0);
+    // Prologue order: first key tile's DMA, then the 128 theta loads (unconditional, from a clamped
+    // position: 128 independent loads in flight; lanes of queries beyond P compute on a duplicate of
+    // query 0 and are discarded), then wait for the DMA only.  VMEM returns in order and s_waitcnt can
+    // express at most vmcnt(63): "at most 63 outstanding" covers the DMA plus the first 65 theta loads, so
+    // the chain starts on its first fragments while the rest are still in flight (the compiler waits
+    // for each asm statement's operands).
+    if (t0 < t1) issue(t0, 0);
+    {
+        const float* tq = th + (unsigned)(hi * P + (qvalid ? query : 0));
+#pragma unroll
+        for (int s = 0; s < CORR_C / 2; ++s) qreg[s] = tq[(unsigned)(2 * s * P)];
     }
-    __syncthreads();  // (drains the LDS-DMA of the first tile)
+    if (t0 < t1) commit(0, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // vmcnt(63) expcnt(7) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
     if (dbgh) dbgh[1] = __builtin_amdgcn_s_memtime();
     long long* dbgp = nullptr;
     if (a.dbg && tid == 0)
