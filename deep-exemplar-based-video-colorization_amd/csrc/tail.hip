@@ -1,0 +1,244 @@
+// Clip-driver tail (/root/reference/test.py:98-116): x2 bilinear upsample of the
+// predicted ab (* 1.25), 8-bit luminance guide, fast global smoother (WLS, cv2.ximgproc in the reference)
+// and Lab -> 8-bit RGB.  All HBM/latency-bound: coalescing and enough independent solves in flight are what
+// matter; nothing here is GEMM-shaped.
+#include "common.h"
+
+// ---- F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) * mul  (test.py:100-102)
+// ATen: src = max(0, 0.5*(dst+0.5) - 0.5), i0 = floor(src), i1 = min(i0+1, S-1), w1 = src - i0, w0 = 1 - w1,
+// and its compiled kernel evaluates w0*a + w1*b as fma(w0, a, fl32(w1*b)) — reproduced bit for bit.
+__device__ __forceinline__ float lerp_aten(float w0, float a, float w1, float b) {
+    return __fmaf_rn(w0, a, __fmul_rn(w1, b));
+}
+__global__ __launch_bounds__(256) void bilinear2x_kernel(const float* __restrict__ x, int H, int W, float mul,
+                                                         float* __restrict__ y) {
+    const int OW = 2 * W, OH = 2 * H;
+    const float* xp = x + (long)blockIdx.y * H * W;
+    float* yp = y + (long)blockIdx.y * OH * OW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < OH * OW; i += gridDim.x * 256) {
+        const int oy = i / OW, ox = i - oy * OW;
+        const float sy = fmaxf(__fsub_rn(__fmul_rn(0.5f, __fadd_rn((float)oy, 0.5f)), 0.5f), 0.f);
+        const float sx = fmaxf(__fsub_rn(__fmul_rn(0.5f, __fadd_rn((float)ox, 0.5f)), 0.5f), 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float wy1 = __fsub_rn(sy, (float)y0), wx1 = __fsub_rn(sx, (float)x0);
+        const float wy0 = __fsub_rn(1.f, wy1), wx0 = __fsub_rn(1.f, wx1);
+        const float top = lerp_aten(wx0, xp[y0 * W + x0], wx1, xp[y0 * W + x1]);
+        const float bot = lerp_aten(wx0, xp[y1 * W + x0], wx1, xp[y1 * W + x1]);
+        yp[i] = __fmul_rn(lerp_aten(wy0, top, wy1, bot), mul);
+    }
+}
+
+extern "C" int dvc_upsample_bilinear2x(const float* x, int32_t planes, int32_t H, int32_t W, float mul, float* y,
+                                       dvcStream stream) {
+    DVC_REQUIRE(x && y && planes > 0 && H > 0 && W > 0, "dvc_upsample_bilinear2x: bad argument");
+    DVC_REQUIRE((long)4 * H * W < (1L << 31), "dvc_upsample_bilinear2x: plane too large");
+    hipLaunchKernelGGL(bilinear2x_kernel, dim3(cdiv(4 * H * W, 1024), planes), dim3(256), 0, (hipStream_t)stream,
+                       x, H, W, mul, y);
+    DVC_CHECK_LAUNCH("dvc_upsample_bilinear2x");
+    return 0;
+}
+
+// ---- (uncenter_l(L) * 255 / 100).astype(uint8)  (test.py:106-109)
+__global__ __launch_bounds__(256) void lum_guide_kernel(const float* __restrict__ L, long n,
+                                                        unsigned char* __restrict__ g) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = __fdiv_rn(__fmul_rn(__fadd_rn(L[i], 50.f), 255.f), 100.f);
+        g[i] = (unsigned char)(int)v;   // numpy astype(uint8): truncation (wraps modulo 256 outside [0,256))
+    }
+}
+extern "C" int dvc_lum_guide_u8(const float* L_centered, int64_t n, uint8_t* guide, dvcStream stream) {
+    DVC_REQUIRE(L_centered && guide && n > 0, "dvc_lum_guide_u8: bad argument");
+    hipLaunchKernelGGL(lum_guide_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
+                       L_centered, (long)n, guide);
+    DVC_CHECK_LAUNCH("dvc_lum_guide_u8");
+    return 0;
+}
+
+// ---- fast global smoother: D. Min et al., "Fast Global Image Smoothing Based on Weighted Least Squares",
+// IEEE TIP 2014, Algorithm 1 (the filter cv2.ximgproc.createFastGlobalSmootherFilter implements).
+// T iterations of { 1-D WLS solve along every row ; along every column } with
+//   lambda_t = 1.5 * 4^(T-t) / (4^T - 1) * lambda,   w(p,q) = exp(-|g_p - g_q| / sigma_color)  (8-bit guide),
+// each 1-D solve a tridiagonal system (a_x = -lambda w(x-1,x), c_x = -lambda w(x,x+1), b_x = 1 - a_x - c_x),
+// Thomas algorithm in float32.
+// Mapping: one thread per LINE; consecutive threads own consecutive lines and march along the other axis, so
+// every load / store of the column solve is a coalesced row.  The row solve runs on the transposed image (a
+// 32x32 LDS-tile transpose before and after).  The sweeps are latency chains (one divide + two fma per
+// element); planes x lines threads (2 x 768 / 2 x 432 at 432x768) are all the parallelism the algorithm has.
+__global__ __launch_bounds__(256) void fgs_weights_kernel(const unsigned char* __restrict__ g, int H, int W,
+                                                          float inv_sigma, float* __restrict__ wv,
+                                                          float* __restrict__ wh_t) {
+    // wv[y][x]   = w((y,x),(y+1,x))   [H][W]   (last row unused)
+    // wh_t[x][y] = w((y,x),(y,x+1))   [W][H]   (last row unused) — the horizontal weights, transposed
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
+        const int y = i / W, x = i - y * W;
+        const int c = g[i];
+        const int dn = y + 1 < H ? abs(c - (int)g[i + W]) : 0;
+        const int rt = x + 1 < W ? abs(c - (int)g[i + 1]) : 0;
+        wv[i] = expf(-(float)dn * inv_sigma);
+        wh_t[(long)x * H + y] = expf(-(float)rt * inv_sigma);
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int H, int W,
+                                                        float* __restrict__ y) {
+    __shared__ float t[32][33];
+    const float* xp = x + (long)blockIdx.z * H * W;
+    float* yp = y + (long)blockIdx.z * H * W;
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (by + r < H && bx + tx < W) t[r][tx] = xp[(long)(by + r) * W + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (bx + r < W && by + tx < H) yp[(long)(bx + r) * H + by + tx] = t[tx][r];
+}
+
+// solve (I + lambda A) u = f along axis 0 of f [planes][L][M] (L = line length, M = number of lines), in place;
+// w [L][M] = weight between element l and l+1 of line m; cp / dp: [planes][L][M] scratch.
+#define FGS_U 16
+__global__ __launch_bounds__(64) void fgs_solve_kernel(float* __restrict__ f, const float* __restrict__ w, int L,
+                                                       int M, float lambda, float* __restrict__ cp,
+                                                       float* __restrict__ dp) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= M) return;
+    float* fp = f + (long)blockIdx.y * L * M + m;
+    float* cpp = cp + (long)blockIdx.y * L * M + m;
+    float* dpp = dp + (long)blockIdx.y * L * M + m;
+    const float* wp = w + m;
+    // forward elimination.  The loads do not depend on the recurrence: fetch FGS_U elements ahead, then run
+    // the FGS_U dependent steps from registers (otherwise every step exposes a global-load latency)
+    float a = 0.f;                                   // a_0 = 0
+    float c = L > 1 ? -lambda * wp[0] : 0.f;
+    float b = 1.f - a - c;
+    float cprev = c / b, dprev = fp[0] / b;
+    cpp[0] = cprev;
+    dpp[0] = dprev;
+    for (int l0 = 1; l0 < L; l0 += FGS_U) {
+        float wk[FGS_U], fk[FGS_U];
+#pragma unroll
+        for (int k = 0; k < FGS_U; ++k) {
+            const int l = l0 + k;
+            wk[k] = l + 1 < L ? wp[(long)l * M] : 0.f;
+            fk[k] = l < L ? fp[(long)l * M] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < FGS_U; ++k) {
+            const int l = l0 + k;
+            if (l < L) {
+                a = c;                               // a_l = -lambda w(l-1,l) = c_{l-1}
+                c = -lambda * wk[k];                 // (0 at the end of the line)
+                b = 1.f - a - c;
+                const float mden = b - a * cprev;
+                cprev = c / mden;
+                dprev = (fk[k] - a * dprev) / mden;
+                cpp[(long)l * M] = cprev;
+                dpp[(long)l * M] = dprev;
+            }
+        }
+    }
+    // back substitution, same prefetch scheme
+    float u = dprev;
+    fp[(long)(L - 1) * M] = u;
+    for (int l0 = L - 2; l0 >= 0; l0 -= FGS_U) {
+        float ck[FGS_U], dk[FGS_U];
+#pragma unroll
+        for (int k = 0; k < FGS_U; ++k) {
+            const int l = l0 - k;
+            ck[k] = l >= 0 ? cpp[(long)l * M] : 0.f;
+            dk[k] = l >= 0 ? dpp[(long)l * M] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < FGS_U; ++k) {
+            const int l = l0 - k;
+            if (l >= 0) {
+                u = dk[k] - ck[k] * u;
+                fp[(long)l * M] = u;
+            }
+        }
+    }
+}
+
+extern "C" size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t planes) {
+    // wv + wh_t + transposed image + cp + dp
+    return sizeof(float) * ((size_t)2 * H * W + (size_t)3 * planes * H * W);
+}
+
+extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t planes, int32_t H, int32_t W,
+                              float lambda, float sigma_color, int32_t num_iter, float lambda_attenuation,
+                              float* dst, void* workspace, size_t workspace_bytes, dvcStream stream) {
+    DVC_REQUIRE(guide && src && dst && workspace && planes > 0 && H > 0 && W > 0, "dvc_fgs_filter: bad argument");
+    DVC_REQUIRE(num_iter >= 1 && num_iter <= 8 && sigma_color > 0.f && lambda >= 0.f, "dvc_fgs_filter: bad parameters");
+    DVC_REQUIRE(workspace_bytes >= dvc_fgs_workspace_bytes(H, W, planes), "dvc_fgs_filter: workspace too small");
+    DVC_REQUIRE((long)H * W < (1L << 30), "dvc_fgs_filter: image too large");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t HW = (size_t)H * W;
+    float* wv = reinterpret_cast<float*>(workspace);
+    float* wh_t = wv + HW;
+    float* tr = wh_t + HW;
+    float* cp = tr + planes * HW;
+    float* dp = cp + planes * HW;
+    hipLaunchKernelGGL(fgs_weights_kernel, dim3(cdiv((int)HW, 1024)), dim3(256), 0, s, guide, H, W,
+                       1.0f / sigma_color, wv, wh_t);
+    DVC_CHECK_LAUNCH("dvc_fgs_filter(weights)");
+    if (dst != src) {
+        hipError_t e = hipMemcpyAsync(dst, src, sizeof(float) * planes * HW, hipMemcpyDeviceToDevice, s);
+        DVC_REQUIRE(e == hipSuccess, "dvc_fgs_filter: copy failed: %s", hipGetErrorString(e));
+    }
+    double lam = 1.5 * (double)lambda * pow(4.0, num_iter - 1) / (pow(4.0, num_iter) - 1.0);
+    float lam_f = (float)lam;
+    const dim3 tgrid_fwd(cdiv(W, 32), cdiv(H, 32), planes), tgrid_bwd(cdiv(H, 32), cdiv(W, 32), planes);
+    for (int it = 0; it < num_iter; ++it) {
+        // rows: transpose -> lines are the W columns of the transposed [W][H] image, length... each ROW of the
+        // image is a line of length W: in the transposed image [W][H] it runs along axis 0 with M = H lines
+        hipLaunchKernelGGL(transpose_kernel, tgrid_fwd, dim3(256), 0, s, dst, H, W, tr);
+        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(H, 64), planes), dim3(64), 0, s, tr, wh_t, W, H, lam_f, cp, dp);
+        hipLaunchKernelGGL(transpose_kernel, tgrid_bwd, dim3(256), 0, s, tr, W, H, dst);
+        // columns
+        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(W, 64), planes), dim3(64), 0, s, dst, wv, H, W, lam_f, cp, dp);
+        DVC_CHECK_LAUNCH("dvc_fgs_filter(solve)");
+        lam_f = lam_f * lambda_attenuation;
+    }
+    return 0;
+}
+
+// ---- batch_lab2rgb_transpose_mc (utils/util.py:134-151) for one image: skimage.color.lab2rgb in float64,
+// clip, * 255, astype(uint8); output HWC.
+__global__ __launch_bounds__(256) void lab2rgb_u8_kernel(const float* __restrict__ L, const float* __restrict__ ab,
+                                                         long HW, unsigned char* __restrict__ rgb) {
+    // inverse of skimage's xyz_from_rgb (its rgb_from_xyz = scipy.linalg.inv(xyz_from_rgb), float64)
+    const double M[3][3] = {{3.240481343200526, -1.5371515162713185, -0.4985363261688878},
+                            {-0.9692549499965682, 1.8759900014898907, 0.04155592655829284},
+                            {0.05564663913517716, -0.20404133836651123, 1.0573110696453443}};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+        const double l = (double)L[i] + 50.0, a = (double)ab[i], b = (double)ab[HW + i];
+        const double fy = (l + 16.0) / 116.0;
+        const double fx = a / 500.0 + fy;
+        double fz = fy - b / 200.0;
+        fz = fz < 0.0 ? 0.0 : fz;
+        double xyz[3] = {fx, fy, fz};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double v = xyz[k];
+            xyz[k] = v > 0.2068966 ? v * v * v : (v - 16.0 / 116.0) / 7.787;
+        }
+        xyz[0] *= 0.95047;
+        xyz[2] *= 1.08883;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double v = xyz[0] * M[k][0] + xyz[1] * M[k][1] + xyz[2] * M[k][2];
+            v = v > 0.0031308 ? 1.055 * pow(v, 1.0 / 2.4) - 0.055 : v * 12.92;
+            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            rgb[3 * i + k] = (unsigned char)(int)(v * 255.0);
+        }
+    }
+}
+extern "C" int dvc_lab2rgb_u8(const float* L_centered, const float* ab, int32_t H, int32_t W, uint8_t* rgb_hwc,
+                              dvcStream stream) {
+    DVC_REQUIRE(L_centered && ab && rgb_hwc && H > 0 && W > 0, "dvc_lab2rgb_u8: bad argument");
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(lab2rgb_u8_kernel, dim3((unsigned)((HW + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
+                       L_centered, ab, HW, rgb_hwc);
+    DVC_CHECK_LAUNCH("dvc_lab2rgb_u8");
+    return 0;
+}

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvc_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -48,6 +48,12 @@ SIGNATURES = {
     "dvc_gray2rgb": (ctypes.c_int, [_VP, c_i32, c_i32, c_i64, _VP, _VP]),
     "dvc_lab2rgb": (ctypes.c_int, [_VP, c_i32, c_i32, ctypes.c_float, _VP, _VP]),
     "dvc_pack_color_input": (ctypes.c_int, [_VP, _VP, _VP, _VP, c_i32, c_i32, _VP, _VP]),
+    "dvc_upsample_bilinear2x": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP]),
+    "dvc_lum_guide_u8": (ctypes.c_int, [_VP, c_i64, _VP, _VP]),
+    "dvc_fgs_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32]),
+    "dvc_fgs_filter": (ctypes.c_int, [_VP, _VP, c_i32, c_i32, c_i32, ctypes.c_float, ctypes.c_float, c_i32,
+                                      ctypes.c_float, _VP, _VP, ctypes.c_size_t, _VP]),
+    "dvc_lab2rgb_u8": (ctypes.c_int, [_VP, _VP, c_i32, c_i32, _VP, _VP]),
     "dvc_corr_prepare": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP]),
     "dvc_corr_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "dvc_corr_fwd": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_float, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,

@@ -1,0 +1,79 @@
+"""Clip-driver tail of /root/reference/test.py:98-116 on the GPU: x2 bilinear upsample
+of the predicted ab (* 1.25), 8-bit luminance guide, fast global smoother (WLS) and Lab -> 8-bit RGB.
+
+The reference does this on the host per frame (D2H copy, single-core OpenCV-contrib filter, float64 skimage
+conversion); here the frame stays in HBM and only the final H x W x 3 uint8 image would leave the device.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .ops import _need, _p, _stream, _workspace
+
+
+def upsample_ab(ab, mul=1.25):
+    """torch.nn.functional.interpolate(ab, scale_factor=2, mode="bilinear") * 1.25   (test.py:100-102)."""
+    lib = _lib.load()
+    _need(ab, "ab")
+    N, C, H, W = ab.shape
+    y = torch.empty((N, C, 2 * H, 2 * W), device=ab.device, dtype=torch.float32)
+    _lib.check(lib.dvc_upsample_bilinear2x(_p(ab), N * C, H, W, float(mul), _p(y), _stream()),
+               "dvc_upsample_bilinear2x")
+    return y
+
+
+def luminance_guide_u8(L_centered):
+    """(uncenter_l(L) * 255 / 100).astype(np.uint8)   (test.py:106-109); any shape, returns uint8 of that shape."""
+    lib = _lib.load()
+    _need(L_centered, "L")
+    g = torch.empty(L_centered.shape, device=L_centered.device, dtype=torch.uint8)
+    _lib.check(lib.dvc_lum_guide_u8(_p(L_centered), L_centered.numel(), ctypes.c_void_p(g.data_ptr()), _stream()),
+               "dvc_lum_guide_u8")
+    return g
+
+
+def fgs_filter(guide_u8, src, lambda_value=500.0, sigma_color=4.0, num_iter=3, lambda_attenuation=0.25):
+    """cv2.ximgproc.createFastGlobalSmootherFilter(guide, lambda, sigma_color).filter(plane) for every plane of
+    `src` [planes, H, W] (test.py:107-111); guide_u8: [H, W] uint8."""
+    lib = _lib.load()
+    _need(src, "src")
+    if guide_u8.dtype != torch.uint8 or not guide_u8.is_cuda or not guide_u8.is_contiguous():
+        raise RuntimeError("dvc_amd: `guide` must be a contiguous uint8 ROCm tensor")
+    planes, H, W = src.shape
+    if tuple(guide_u8.shape) != (H, W):
+        raise RuntimeError(f"dvc_amd: guide shape {tuple(guide_u8.shape)} != {(H, W)}")
+    dst = torch.empty_like(src)
+    ws = _workspace(src.device, lib.dvc_fgs_workspace_bytes(H, W, planes), "fgs")
+    _lib.check(lib.dvc_fgs_filter(ctypes.c_void_p(guide_u8.data_ptr()), _p(src), planes, H, W, float(lambda_value),
+                                  float(sigma_color), int(num_iter), float(lambda_attenuation), _p(dst),
+                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "dvc_fgs_filter")
+    return dst
+
+
+def lab_to_rgb8(L_centered, ab):
+    """batch_lab2rgb_transpose_mc(L[:1], ab[:1]) (utils/util.py:134-151): [H,W] + [2,H,W] -> uint8 [H,W,3]."""
+    lib = _lib.load()
+    _need(L_centered, "L")
+    _need(ab, "ab")
+    H, W = L_centered.shape[-2:]
+    rgb = torch.empty((H, W, 3), device=ab.device, dtype=torch.uint8)
+    _lib.check(lib.dvc_lab2rgb_u8(_p(L_centered), _p(ab), H, W, ctypes.c_void_p(rgb.data_ptr()), _stream()),
+               "dvc_lab2rgb_u8")
+    return rgb
+
+
+def frame_tail(IA_lab_large, I_current_ab_predict, wls_filter_on=True, lambda_value=500, sigma_color=4):
+    """test.py:98-116 for one frame (batch 1): returns (IA_predict_rgb uint8 [2H,2W,3] on the device,
+    curr_predict[_filter] float32 [1,2,2H,2W]).  Names follow the reference."""
+    if IA_lab_large.shape[0] != 1 or I_current_ab_predict.shape[0] != 1:
+        raise RuntimeError("frame_tail: batch 1 only (the reference filters image 0 of the batch, test.py:108-110)")
+    curr_bs_l = IA_lab_large[:, 0:1, :, :].contiguous()
+    curr_predict = upsample_ab(I_current_ab_predict.detach().contiguous().float())
+    if tuple(curr_predict.shape[-2:]) != tuple(curr_bs_l.shape[-2:]):
+        raise RuntimeError(f"frame_tail: upsampled ab {tuple(curr_predict.shape[-2:])} vs L {tuple(curr_bs_l.shape[-2:])}")
+    if wls_filter_on:
+        guide_image = luminance_guide_u8(curr_bs_l[0, 0])
+        curr_predict = fgs_filter(guide_image, curr_predict[0], lambda_value, sigma_color).unsqueeze(0)
+    IA_predict_rgb = lab_to_rgb8(curr_bs_l[0, 0], curr_predict[0])
+    return IA_predict_rgb, curr_predict

@@ -27,7 +27,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 3
+#define DVC_ABI_VERSION 4
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -159,6 +159,26 @@ int dvc_lab2rgb(const float* lab, int32_t N, int32_t HW, float l_offset, float* 
 int dvc_pack_color_input(const float* IA_lab, const float* warped_lab, const float* sim,
                          const float* IA_last_lab, int32_t N, int32_t HW, float* out7,
                          dvcStream stream);
+
+/* ---- clip-driver tail, test.py:98-116 ------------------------------------------------
+ * F.interpolate(x, scale_factor=2, mode="bilinear") * mul on `planes` planes of H x W (test.py:100-102; ATen's
+ * align_corners=False source index and its fma evaluation order, bit-exact for the sizes the path uses). */
+int dvc_upsample_bilinear2x(const float* x, int32_t planes, int32_t H, int32_t W, float mul, float* y,
+                            dvcStream stream);
+/* (uncenter_l(L) * 255 / 100).astype(uint8): the guide image of the WLS filter, test.py:106-109. */
+int dvc_lum_guide_u8(const float* L_centered, int64_t n, uint8_t* guide, dvcStream stream);
+/* cv2.ximgproc.createFastGlobalSmootherFilter(guide, lambda, sigma_color).filter(src) on `planes` float planes
+ * (test.py:107-111): Min et al. 2014, Alg. 1 — num_iter x {row solve, column solve}, lambda_t = 1.5 * 4^(T-t) /
+ * (4^T - 1) * lambda, weights exp(-|dg| / sigma_color).  OpenCV's defaults: num_iter 3, attenuation 0.25.
+ * dst may be src.  Parity unpinned (opencv-contrib is absent from the build image; see oracle/tail_oracle.py). */
+size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t planes);
+int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t planes, int32_t H, int32_t W, float lambda,
+                   float sigma_color, int32_t num_iter, float lambda_attenuation, float* dst, void* workspace,
+                   size_t workspace_bytes, dvcStream stream);
+/* batch_lab2rgb_transpose_mc for one image (utils/util.py:134-151): Lab (L centred) -> skimage lab2rgb (float64)
+ * -> clip -> *255 -> uint8, H x W x 3.  ab = [2][H][W].  Parity unpinned (skimage absent). */
+int dvc_lab2rgb_u8(const float* L_centered, const float* ab, int32_t H, int32_t W, uint8_t* rgb_hwc,
+                   dvcStream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense correlation (the north-star kernel).  Replaces models/NonlocalNet.py:469-500:

@@ -1,0 +1,110 @@
+"""Clip-driver tail (test.py:98-116).
+
+CPU: the oracle's bilinear x2 restatement against the call the reference itself makes
+(torch.nn.functional.interpolate), and properties of the WLS restatement (cv2.ximgproc is absent: parity of
+the filter is unpinned, see oracle/tail_oracle.py).  GPU: the HIP kernels against the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tail_oracle as T
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 54, 96), (1, 2, 216, 384), (1, 2, 108, 192)])
+def test_oracle_bilinear_matches_aten_bitwise(shape):
+    """The shapes the path produces (batch 1, the two ab planes): bit-exact against the reference's own call."""
+    torch.set_num_threads(1)
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(1)) * 40
+    ref = (F.interpolate(x, scale_factor=2, mode="bilinear") * 1.25).numpy()
+    assert np.array_equal(T.upsample_ab(x.numpy()), ref)
+
+
+def test_oracle_bilinear_other_shapes_within_2ulp():
+    """For other shapes ATen's TensorIterator may pick another inner loop (different fma contraction): <= 2 ulp."""
+    for shape in [(1, 2, 13, 24), (2, 3, 7, 5), (1, 1, 1, 1), (2, 3, 40, 64)]:
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(2)) * 40
+        ref = (F.interpolate(x, scale_factor=2, mode="bilinear") * 1.25).numpy()
+        got = T.upsample_ab(x.numpy())
+        assert np.abs(got - ref).max() <= 2 * np.spacing(np.abs(ref).max().astype(np.float32))
+
+
+def test_oracle_guide_and_fgs_properties():
+    rng = np.random.default_rng(0)
+    L = (rng.random((40, 60)) * 100 - 50).astype(np.float32)
+    g = T.luminance_guide_u8(L)
+    assert g.dtype == np.uint8 and np.array_equal(g, ((L + 50) * 255 / 100).astype(np.uint8))
+    f = rng.standard_normal((40, 60)).astype(np.float32) * 20
+    u = T.fgs_filter(g, f)
+    # (I + lambda A) with A a graph Laplacian: constants are fixed points, the mean is preserved, energy drops
+    assert np.abs(T.fgs_filter(g, np.full_like(f, 3.25)) - 3.25).max() < 1e-3
+    assert abs(float(u.mean()) - float(f.mean())) < 1e-3
+    assert u.var() < f.var()
+    # lambda = 0 is the identity; an edge in the guide stops the smoothing across it
+    assert np.abs(T.fgs_filter(g, f, lambda_value=0.0) - f).max() < 1e-6
+    gs = np.zeros((16, 32), np.uint8)
+    gs[:, 16:] = 255
+    step = np.where(np.arange(32) < 16, -10.0, 10.0).astype(np.float32)[None].repeat(16, 0)
+    noisy = step + rng.standard_normal(step.shape).astype(np.float32)
+    sm = T.fgs_filter(gs, noisy)
+    assert sm[:, :16].max() < -8 and sm[:, 16:].min() > 8 and sm[:, :16].std() < 0.2
+
+
+def test_oracle_lab_to_rgb8_known_values():
+    L = np.array([[50.0, -50.0, 50.0, 3.24]], np.float32)      # centred: L* = 100, 0, 100, 53.24
+    ab = np.array([[[0.0, 0.0, 0.0, 80.09]], [[0.0, 0.0, 0.0, 67.20]]], np.float32)
+    rgb = T.lab_to_rgb8(L, ab)
+    assert rgb.shape == (1, 4, 3) and rgb.dtype == np.uint8
+    assert (rgb[0, 0] >= 254).all() and (rgb[0, 1] == 0).all()
+    assert rgb[0, 3, 0] >= 253 and rgb[0, 3, 1] <= 2 and rgb[0, 3, 2] <= 2      # sRGB red = Lab(53.24, 80.09, 67.20)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 2, 54, 96), (1, 2, 216, 384), (2, 3, 13, 24), (1, 1, 1, 7)])
+def test_gpu_bilinear_matches_oracle_bitwise(shape):
+    from dvc_amd import tail
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(3)) * 40
+    got = tail.upsample_ab(x.cuda()).cpu().numpy()
+    assert np.array_equal(got, T.upsample_ab(x.numpy()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(40, 60), (108, 192), (33, 70), (432, 768)])
+def test_gpu_tail_matches_oracle(hw, report=print):
+    from dvc_amd import tail
+    H, W = hw
+    g = torch.Generator().manual_seed(H)
+    base = F.interpolate(torch.rand(1, 1, max(H // 8, 1), max(W // 8, 1), generator=g), (H, W), mode="bilinear")
+    L = (base + 0.05 * torch.rand(1, 1, H, W, generator=g)).clamp(0, 1) * 100 - 50
+    src = torch.randn(2, H, W, generator=g) * 30
+    guide = tail.luminance_guide_u8(L[0, 0].cuda())
+    assert np.array_equal(guide.cpu().numpy(), T.luminance_guide_u8(L[0, 0].numpy()))
+    got = tail.fgs_filter(guide, src.cuda()).cpu().numpy()
+    ref = np.stack([T.fgs_filter(guide.cpu().numpy(), src[k].numpy()) for k in range(2)])
+    err = np.abs(got - ref).max()
+    print(f"fgs {H}x{W}: max abs err vs oracle {err:.2e} (values ~{np.abs(ref).max():.1f})")
+    assert err < 2e-3
+    rgb = tail.lab_to_rgb8(L[0, 0].cuda(), torch.from_numpy(ref).cuda()).cpu().numpy()
+    ref8 = T.lab_to_rgb8(L[0, 0].numpy(), ref)
+    d = np.abs(rgb.astype(np.int32) - ref8.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_frame_tail_end_to_end():
+    from dvc_amd import tail
+    H, W = 54, 96
+    g = torch.Generator().manual_seed(9)
+    L = torch.rand(1, 1, 2 * H, 2 * W, generator=g) * 100 - 50
+    lab_large = torch.cat((L, torch.zeros(1, 2, 2 * H, 2 * W)), 1)
+    ab = torch.randn(1, 2, H, W, generator=g) * 25
+    rgb, cur = tail.frame_tail(lab_large.cuda(), ab.cuda())
+    rgb_o, cur_o = T.frame_tail(L.numpy(), ab.numpy())
+    assert np.abs(cur.cpu().numpy() - cur_o).max() < 2e-3
+    d = np.abs(rgb.cpu().numpy().astype(np.int32) - rgb_o.astype(np.int32))
+    assert d.max() <= 1
+    rgb2, cur2 = tail.frame_tail(lab_large.cuda(), ab.cuda(), wls_filter_on=False)
+    assert np.array_equal(cur2.cpu().numpy(), T.upsample_ab(ab.numpy()))
+    with pytest.raises(RuntimeError):
+        tail.frame_tail(lab_large, ab)          # CPU tensors: no fallback
