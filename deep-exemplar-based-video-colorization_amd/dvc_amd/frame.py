@@ -69,6 +69,7 @@ class ClipColorizer:
         self.last_lab = None         # [L, ab] of the last frame colourised by clip()
         self._side_streams = []
         self._main_stream = None
+        self._tail_stream = None
 
     def set_exemplar(self, IB_lab):
         """test.py:61-66: Lab -> RGB -> VGG features of the reference image."""
@@ -96,7 +97,7 @@ class ClipColorizer:
                                        temperature=self.temperature, exemplar_cache=self.ex_cache)
         return ab, nl
 
-    def clip(self, frames_lab, frame_propagate=False, last=None, lookahead=2):
+    def clip(self, frames_lab, frame_propagate=False, last=None, lookahead=2, on_frame=None):
         """Recurrence of test.py:68-96; returns the list of ab predictions.
 
         Only ColorVidNet(t) consumes frame t-1's prediction (test.py:96 -> FrameColor.py:63-64); the
@@ -105,7 +106,9 @@ class ClipColorizer:
         streams while the current stream runs the ColorVidNet chain, so their workgroups fill the CUs
         the other stream's layer leaves idle (few-tile layers, tail rounds).  Same kernels, same
         per-frame arithmetic and order: the predictions are bit-identical to the sequential loop.
-        `last` (optional) continues the recurrence from an earlier call."""
+        `last` (optional) continues the recurrence from an earlier call.  `on_frame(t, IA_lab, ab)`
+        (optional) is called right after frame t's launches have been issued, with the recurrence stream
+        current — the hook `clip_rgb` hangs the per-frame tail on."""
         frames_lab = list(frames_lab)
         if not frames_lab:
             return []
@@ -117,6 +120,8 @@ class ClipColorizer:
                 ab, _ = self.frame(IA_lab, last)
                 last = torch.cat((IA_lab[:, 0:1], ab), dim=1)   # test.py:96 (pure data movement)
                 outs.append(ab)
+                if on_frame is not None:
+                    on_frame(len(outs) - 1, IA_lab, ab)
             self.last_lab = last
             return outs
         caller = torch.cuda.current_stream()
@@ -156,6 +161,8 @@ class ClipColorizer:
                 color_input = ops.pack_color_input(IA_lab, warped, sim, last.detach().contiguous().float())
                 ab = self.col(color_input)
                 last = torch.cat((IA_lab[:, 0:1], ab), dim=1)
+                if on_frame is not None:
+                    on_frame(t, IA_lab, ab)
             outs.append(ab)
             if t + lookahead < T:       # (issued after the critical-path launches of frame t)
                 launch_front(t + lookahead)
@@ -164,3 +171,33 @@ class ClipColorizer:
             x.record_stream(caller)     # allocated on the recurrence stream, handed to the caller's stream
         self.last_lab = last
         return outs
+
+    def clip_rgb(self, frames_lab_large, wls_filter_on=True, lambda_value=500, sigma_color=4, frame_propagate=False,
+                 lookahead=2):
+        """The device-side part of the whole per-frame loop of test.py:68-116: full-resolution Lab frames
+        (what `transform(...)` yields, test.py:70) -> x0.5 bilinear -> frame_colorization recurrence -> x2
+        bilinear * 1.25 -> WLS filter -> 8-bit RGB (H x W x 3 uint8 device tensors, one per frame).
+        The tail of frame t runs on its own low-priority stream, off the recurrence's critical path."""
+        from . import tail
+        frames_lab_large = [f.detach().contiguous().float() for f in frames_lab_large]
+        small = [tail.downsample_half(f) for f in frames_lab_large]
+        caller = torch.cuda.current_stream()
+        if self._tail_stream is None:
+            self._tail_stream = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[0])
+        ts = self._tail_stream
+        ts.wait_stream(caller)
+        rgbs = [None] * len(small)
+
+        def on_frame(t, IA_lab, ab):
+            ev = torch.cuda.Event()
+            ev.record()                         # on the stream that produced `ab`
+            ab.record_stream(ts)
+            ts.wait_event(ev)
+            with torch.cuda.stream(ts):
+                rgbs[t], _ = tail.frame_tail(frames_lab_large[t], ab, wls_filter_on, lambda_value, sigma_color)
+
+        self.clip(small, frame_propagate=frame_propagate, lookahead=lookahead, on_frame=on_frame)
+        caller.wait_stream(ts)
+        for x in rgbs:
+            x.record_stream(caller)
+        return rgbs

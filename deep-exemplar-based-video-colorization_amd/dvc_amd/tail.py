@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .ops import _need, _p, _stream, _workspace
+from .ops import _need, _p, _stream, _workspace, avgpool2x2
 
 
 def upsample_ab(ab, mul=1.25):
@@ -21,6 +21,12 @@ def upsample_ab(ab, mul=1.25):
     _lib.check(lib.dvc_upsample_bilinear2x(_p(ab), N * C, H, W, float(mul), _p(y), _stream()),
                "dvc_upsample_bilinear2x")
     return y
+
+
+def downsample_half(x):
+    """torch.nn.functional.interpolate(x, scale_factor=0.5, mode="bilinear")   (test.py:58,71) — which ATen
+    evaluates exactly as a 2x2 average pool (checked bit for bit in tests/test_tail.py)."""
+    return avgpool2x2(x)
 
 
 def luminance_guide_u8(L_centered):

@@ -134,7 +134,8 @@ int dvc_instnorm_apply(const float* x, const float* residual /* or NULL */, cons
 
 /* nn.MaxPool2d(2,2) floor mode, NonlocalNet.py:237-255. planes = N*C. */
 int dvc_maxpool2x2(const float* x, int32_t planes, int32_t H, int32_t W, float* y, dvcStream stream);
-/* nn.AvgPool2d(2,2): the pool="avg" variant of VGG19_pytorch, NonlocalNet.py:221-226. */
+/* nn.AvgPool2d(2,2): the pool="avg" variant of VGG19_pytorch, NonlocalNet.py:221-226; also, bit for bit,
+ * F.interpolate(x, scale_factor=0.5, mode="bilinear") — full-resolution Lab -> network resolution, test.py:58,71. */
 int dvc_avgpool2x2(const float* x, int32_t planes, int32_t H, int32_t W, float* y, dvcStream stream);
 /* F.avg_pool2d(x, 4), NonlocalNet.py:491. */
 int dvc_avgpool4x4(const float* x, int32_t planes, int32_t H, int32_t W, float* y, dvcStream stream);

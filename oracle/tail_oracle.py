@@ -59,6 +59,18 @@ def upsample_ab(ab):
     return (out * np.float32(1.25)).astype(np.float32)
 
 
+def downsample_half(x):
+    """F.interpolate(x, scale_factor=0.5, mode='bilinear') (test.py:58,71).  ATen evaluates it exactly like
+    F.avg_pool2d(x, 2): ((x00 + x01) + x10) + x11, then * 0.25 (pinned against both calls in tests/test_tail.py)."""
+    x = np.asarray(x, dtype=np.float32)
+    H2, W2 = x.shape[2] // 2, x.shape[3] // 2
+    x = x[:, :, :2 * H2, :2 * W2]
+    s = (x[:, :, 0::2, 0::2] + x[:, :, 0::2, 1::2]).astype(np.float32)
+    s = (s + x[:, :, 1::2, 0::2]).astype(np.float32)
+    s = (s + x[:, :, 1::2, 1::2]).astype(np.float32)
+    return (s * np.float32(0.25)).astype(np.float32)
+
+
 def luminance_guide_u8(L_centered):
     """(uncenter_l(L) * 255 / 100).astype(uint8): test.py:106-109, utils/util.py:63-64."""
     L = np.asarray(L_centered, dtype=np.float32)

@@ -29,6 +29,15 @@ def test_oracle_bilinear_other_shapes_within_2ulp():
         assert np.abs(got - ref).max() <= 2 * np.spacing(np.abs(ref).max().astype(np.float32))
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 432, 768), (1, 3, 216, 384), (2, 3, 41, 65), (1, 1, 2, 2)])
+def test_oracle_downsample_half_matches_aten_bitwise(shape):
+    torch.set_num_threads(1)
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(4)) * 40
+    ref = F.interpolate(x, scale_factor=0.5, mode="bilinear").numpy()
+    assert np.array_equal(T.downsample_half(x.numpy()), ref)
+    assert np.array_equal(F.avg_pool2d(x, 2).numpy(), ref)
+
+
 def test_oracle_guide_and_fgs_properties():
     rng = np.random.default_rng(0)
     L = (rng.random((40, 60)) * 100 - 50).astype(np.float32)
@@ -70,6 +79,14 @@ def test_gpu_bilinear_matches_oracle_bitwise(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 3, 432, 768), (2, 3, 41, 65)])
+def test_gpu_downsample_half_matches_oracle_bitwise(shape):
+    from dvc_amd import tail
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(5)) * 40
+    assert np.array_equal(tail.downsample_half(x.cuda()).cpu().numpy(), T.downsample_half(x.numpy()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hw", [(40, 60), (108, 192), (33, 70), (432, 768)])
 def test_gpu_tail_matches_oracle(hw, report=print):
     from dvc_amd import tail
@@ -108,3 +125,32 @@ def test_gpu_frame_tail_end_to_end():
     assert np.array_equal(cur2.cpu().numpy(), T.upsample_ab(ab.numpy()))
     with pytest.raises(RuntimeError):
         tail.frame_tail(lab_large, ab)          # CPU tensors: no fallback
+
+
+@pytest.mark.gpu
+def test_gpu_clip_rgb_equals_stagewise():
+    """ClipColorizer.clip_rgb (x0.5 -> pipelined recurrence -> tail on its own stream) == the same stages called
+    one after the other on one stream."""
+    import contextlib
+    import io
+    from dvc_amd import synth, tail
+    from dvc_amd.frame import ClipColorizer
+    from models.ColorVidNet import ColorVidNet
+    from models.NonlocalNet import VGG19_pytorch, WarpNet
+    dev = torch.device("cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        nets = (VGG19_pytorch(), WarpNet(1), ColorVidNet(7))
+    for m, sd in zip(nets, (synth.vgg19_state_dict(0), synth.warpnet_state_dict(0), synth.colorvidnet_state_dict(0))):
+        m.load_state_dict(sd)
+        m.eval().to(dev)
+    H, W = 96, 160                                  # full resolution; the networks run at 48 x 80
+    large = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W).to(dev) for i in range(5)]
+    cc = ClipColorizer(*nets, temperature=1e-10)
+    cc.set_exemplar(tail.downsample_half(synth.synth_lab(synth.EXEMPLAR_SEED, H, W).to(dev)))
+    got = cc.clip_rgb(large)
+    torch.cuda.synchronize()
+    abs_ = cc.clip([tail.downsample_half(f) for f in large], lookahead=0)
+    for t, (f, ab) in enumerate(zip(large, abs_)):
+        rgb, _ = tail.frame_tail(f, ab)
+        assert got[t].shape == (H, W, 3) and got[t].dtype == torch.uint8
+        assert torch.equal(got[t], rgb), t
