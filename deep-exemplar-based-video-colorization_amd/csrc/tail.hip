@@ -242,3 +242,41 @@ extern "C" int dvc_lab2rgb_u8(const float* L_centered, const float* ab, int32_t 
     DVC_CHECK_LAUNCH("dvc_lab2rgb_u8");
     return 0;
 }
+
+// ---- frame ingest, colour part: RGB2Lab() -> ToTensor() -> Normalize()
+// (utils/util_distortion.py:18-23,85-100, lib/functional.py:85-103): skimage.color.rgb2lab in float64 on the
+// 8-bit image, .float(), L - 50.  Output [3][H][W] float32.  (The geometric part — CenterPad / CenterCrop with
+// skimage's anti-aliased resize — stays on the host.)
+__global__ __launch_bounds__(256) void rgb8_to_lab_kernel(const unsigned char* __restrict__ rgb, long HW,
+                                                          float* __restrict__ lab) {
+    const double M[3][3] = {{0.412453, 0.357580, 0.180423},
+                            {0.212671, 0.715160, 0.072169},
+                            {0.019334, 0.119193, 0.950227}};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+        double c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double v = (double)rgb[3 * i + k] / 255.0;
+            c[k] = v > 0.04045 ? pow((v + 0.055) / 1.055, 2.4) : v / 12.92;
+        }
+        double xyz[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xyz[k] = c[0] * M[k][0] + c[1] * M[k][1] + c[2] * M[k][2];
+        xyz[0] /= 0.95047;
+        xyz[2] /= 1.08883;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xyz[k] = xyz[k] > 0.008856 ? cbrt(xyz[k]) : 7.787 * xyz[k] + 16.0 / 116.0;
+        const float L = (float)(116.0 * xyz[1] - 16.0);
+        lab[i] = L - 50.0f;                                   // Normalize(): (L - 50) / 1 in float32
+        lab[HW + i] = (float)(500.0 * (xyz[0] - xyz[1]));
+        lab[2 * HW + i] = (float)(200.0 * (xyz[1] - xyz[2]));
+    }
+}
+extern "C" int dvc_rgb8_to_lab(const uint8_t* rgb_hwc, int32_t H, int32_t W, float* lab, dvcStream stream) {
+    DVC_REQUIRE(rgb_hwc && lab && H > 0 && W > 0, "dvc_rgb8_to_lab: bad argument");
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(rgb8_to_lab_kernel, dim3((unsigned)((HW + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
+                       rgb_hwc, HW, lab);
+    DVC_CHECK_LAUNCH("dvc_rgb8_to_lab");
+    return 0;
+}

@@ -69,6 +69,18 @@ def lab_to_rgb8(L_centered, ab):
     return rgb
 
 
+def rgb8_to_lab(rgb_hwc):
+    """Normalize()(ToTensor()(RGB2Lab()(image))) (utils/util_distortion.py:18-23,85-100) for an 8-bit H x W x 3
+    device image: returns the centred Lab tensor [1, 3, H, W] that test.py:70 calls `IA_lab_large`."""
+    lib = _lib.load()
+    if rgb_hwc.dtype != torch.uint8 or not rgb_hwc.is_cuda or not rgb_hwc.is_contiguous() or rgb_hwc.shape[-1] != 3:
+        raise RuntimeError("dvc_amd: `rgb` must be a contiguous uint8 ROCm tensor [H, W, 3]")
+    H, W = rgb_hwc.shape[:2]
+    lab = torch.empty((1, 3, H, W), device=rgb_hwc.device, dtype=torch.float32)
+    _lib.check(lib.dvc_rgb8_to_lab(ctypes.c_void_p(rgb_hwc.data_ptr()), H, W, _p(lab), _stream()), "dvc_rgb8_to_lab")
+    return lab
+
+
 def frame_tail(IA_lab_large, I_current_ab_predict, wls_filter_on=True, lambda_value=500, sigma_color=4):
     """test.py:98-116 for one frame (batch 1): returns (IA_predict_rgb uint8 [2H,2W,3] on the device,
     curr_predict[_filter] float32 [1,2,2H,2W]).  Names follow the reference."""

@@ -180,6 +180,10 @@ int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t planes, int32
  * -> clip -> *255 -> uint8, H x W x 3.  ab = [2][H][W].  Parity unpinned (skimage absent). */
 int dvc_lab2rgb_u8(const float* L_centered, const float* ab, int32_t H, int32_t W, uint8_t* rgb_hwc,
                    dvcStream stream);
+/* Frame ingest, colour part: RGB2Lab() -> ToTensor() -> Normalize(),
+ * utils/util_distortion.py:18-23,85-100: skimage rgb2lab (float64) of an 8-bit H x W x 3 image, .float(), L - 50;
+ * lab = [3][H][W].  Parity unpinned (skimage absent); round trip with dvc_lab2rgb_u8 tested. */
+int dvc_rgb8_to_lab(const uint8_t* rgb_hwc, int32_t H, int32_t W, float* lab, dvcStream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense correlation (the north-star kernel).  Replaces models/NonlocalNet.py:469-500:

@@ -144,6 +144,21 @@ def lab_to_rgb8(L_centered, ab):
     return (np.clip(rgb, 0.0, 1.0) * 255.0).astype(np.uint8)
 
 
+def rgb8_to_lab(rgb_hwc):
+    """Normalize()(ToTensor()(RGB2Lab()(image))): skimage.color.rgb2lab (float64) of a uint8 H x W x 3 image,
+    .float(), L - 50 (utils/util_distortion.py:18-23,85-100, lib/functional.py:85-103).  Returns [3,H,W] float32.
+    Parity unpinned (skimage absent): the published sRGB -> XYZ (D65) -> CIELAB formulas skimage implements."""
+    c = np.asarray(rgb_hwc, dtype=np.uint8).astype(np.float64) / 255.0
+    c = np.where(c > 0.04045, np.power((c + 0.055) / 1.055, 2.4), c / 12.92)
+    xyz = c @ _XYZ_FROM_RGB.T
+    xyz = xyz / _D65
+    f = np.where(xyz > 0.008856, np.cbrt(xyz), 7.787 * xyz + 16.0 / 116.0)
+    L = (116.0 * f[..., 1] - 16.0).astype(np.float32) - np.float32(50.0)
+    a = (500.0 * (f[..., 0] - f[..., 1])).astype(np.float32)
+    b = (200.0 * (f[..., 1] - f[..., 2])).astype(np.float32)
+    return np.stack([L, a, b]).astype(np.float32)
+
+
 def frame_tail(L_large_centered, ab_predict, wls_filter_on=True, lambda_value=500.0, sigma_color=4.0):
     """test.py:98-116 for batch 1.  L_large_centered: [1,1,2H,2W], ab_predict: [1,2,H,W].
     Returns (rgb uint8 [2H,2W,3], filtered ab float32 [1,2,2H,2W])."""

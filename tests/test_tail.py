@@ -68,6 +68,20 @@ def test_oracle_lab_to_rgb8_known_values():
     assert rgb[0, 3, 0] >= 253 and rgb[0, 3, 1] <= 2 and rgb[0, 3, 2] <= 2      # sRGB red = Lab(53.24, 80.09, 67.20)
 
 
+def test_oracle_rgb_lab_round_trip():
+    """rgb8 -> Lab -> rgb8 through the two (unpinned, but mutually inverse) restatements: within one level
+    (the final astype(uint8) truncates), and the CIELAB anchors come out right."""
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    rgb[0, 0], rgb[0, 1], rgb[0, 2] = (255, 255, 255), (0, 0, 0), (255, 0, 0)
+    lab = T.rgb8_to_lab(rgb)
+    assert abs(lab[0, 0, 0] - 50.0) < 1e-3 and abs(lab[1, 0, 0]) < 1e-2 and abs(lab[2, 0, 0]) < 1e-2     # white
+    assert abs(lab[0, 0, 1] + 50.0) < 1e-4                                                          # black
+    assert np.abs(lab[:, 0, 2] - np.array([53.2408 - 50, 80.0925, 67.2032])).max() < 2e-2              # sRGB red
+    back = T.lab_to_rgb8(lab[0], lab[1:])
+    assert np.abs(back.astype(np.int32) - rgb.astype(np.int32)).max() <= 1
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 2, 54, 96), (1, 2, 216, 384), (2, 3, 13, 24), (1, 1, 1, 7)])
@@ -154,3 +168,17 @@ def test_gpu_clip_rgb_equals_stagewise():
         rgb, _ = tail.frame_tail(f, ab)
         assert got[t].shape == (H, W, 3) and got[t].dtype == torch.uint8
         assert torch.equal(got[t], rgb), t
+
+
+
+@pytest.mark.gpu
+def test_gpu_rgb8_to_lab_matches_oracle_and_round_trips():
+    from dvc_amd import tail
+    rng = np.random.default_rng(2)
+    rgb = rng.integers(0, 256, (70, 130, 3), dtype=np.uint8)
+    lab = tail.rgb8_to_lab(torch.from_numpy(rgb).cuda())
+    ref = T.rgb8_to_lab(rgb)
+    assert tuple(lab.shape) == (1, 3, 70, 130)
+    assert np.abs(lab[0].cpu().numpy() - ref).max() < 1e-4
+    back = tail.lab_to_rgb8(lab[0, 0].contiguous(), lab[0, 1:].contiguous()).cpu().numpy()
+    assert np.abs(back.astype(np.int32) - rgb.astype(np.int32)).max() <= 1
