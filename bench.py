@@ -5,11 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" = one `frame_colorization` pass (VGG19(A) -> WarpNet(A) + fused correlation -> ColorVidNet)
-on one synthetic 1x3x216x384 Lab frame already resident in HBM, inside the clip recurrence of
-/root/reference/test.py:68-96 (frame t consumes frame t-1's prediction).  N=1 runs BASELINE.json
-configs[1].  With N>1 each rank colourises its own contiguous chunk of K frames (weak scaling; the
-exemplar-side tensors are computed on rank 0 and broadcast once over RCCL/xGMI; no collective in
+A "step" = one frame of the clip recurrence of /root/reference/test.py:68-96 (frame t consumes frame t-1's
+prediction): VGG19(A) -> WarpNet(A) + fused correlation -> ColorVidNet on one synthetic 1x3x216x384 Lab frame
+already resident in HBM.  The K timed steps go through `ClipColorizer.clip` (front end of the next frames on side
+HIP streams, ColorVidNet recurrence on the main one; bit-identical to per-frame `frame_colorization` calls, which
+are timed right after and reported as `config.per_frame_api_frames_per_s`; `--lookahead 0` times those instead).
+N=1 runs BASELINE.json configs[1].  With N>1 each rank colourises its own contiguous chunk of K frames (weak
+scaling; the exemplar-side tensors are computed on rank 0 and broadcast once over RCCL/xGMI; no collective in
 the per-frame path).  Rank 0 prints ONE JSON line on stdout; diagnostics go to stderr.
 """
 import argparse

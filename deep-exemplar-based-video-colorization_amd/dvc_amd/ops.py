@@ -149,6 +149,7 @@ if _autotune:
     _load_tuned()  # env-enabled autotune: pick up a persisted table
 
 
+# split-K candidates of the autotuner (DVC_TUNE_SPLITS=1 disables split-K: experiments only)
 _TUNE_SPLITS = tuple(int(v) for v in _os.environ.get("DVC_TUNE_SPLITS", "1,2,3,4,6,8").split(","))
 
 
