@@ -70,6 +70,9 @@ __global__ __launch_bounds__(256) void fgs_weights_kernel(const unsigned char* _
                                                           float* __restrict__ wh_t) {
     // wv[y][x]   = w((y,x),(y+1,x))   [H][W]   (last row unused)
     // wh_t[x][y] = w((y,x),(y,x+1))   [W][H]   (last row unused) — the horizontal weights, transposed
+    g += (long)blockIdx.y * H * W;
+    wv += (long)blockIdx.y * H * W;
+    wh_t += (long)blockIdx.y * H * W;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
         const int y = i / W, x = i - y * W;
         const int c = g[i];
@@ -98,14 +101,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // w [L][M] = weight between element l and l+1 of line m; cp / dp: [planes][L][M] scratch.
 #define FGS_U 16
 __global__ __launch_bounds__(64) void fgs_solve_kernel(float* __restrict__ f, const float* __restrict__ w, int L,
-                                                       int M, float lambda, float* __restrict__ cp,
-                                                       float* __restrict__ dp) {
+                                                       int M, int planes_per_guide, float lambda,
+                                                       float* __restrict__ cp, float* __restrict__ dp) {
     const int m = blockIdx.x * 64 + threadIdx.x;
     if (m >= M) return;
     float* fp = f + (long)blockIdx.y * L * M + m;
     float* cpp = cp + (long)blockIdx.y * L * M + m;
     float* dpp = dp + (long)blockIdx.y * L * M + m;
-    const float* wp = w + m;
+    const float* wp = w + (long)(blockIdx.y / planes_per_guide) * L * M + m;
     // forward elimination.  The loads do not depend on the recurrence: fetch FGS_U elements ahead, then run
     // the FGS_U dependent steps from registers (otherwise every step exposes a global-load latency)
     float a = 0.f;                                   // a_0 = 0
@@ -159,26 +162,30 @@ __global__ __launch_bounds__(64) void fgs_solve_kernel(float* __restrict__ f, co
     }
 }
 
-extern "C" size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t planes) {
-    // wv + wh_t + transposed image + cp + dp
-    return sizeof(float) * ((size_t)2 * H * W + (size_t)3 * planes * H * W);
+extern "C" size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t n_guides, int32_t planes_per_guide) {
+    // per guide: wv + wh_t; per plane: transposed image + cp + dp
+    return sizeof(float) * ((size_t)2 * n_guides * H * W + (size_t)3 * n_guides * planes_per_guide * H * W);
 }
 
-extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t planes, int32_t H, int32_t W,
-                              float lambda, float sigma_color, int32_t num_iter, float lambda_attenuation,
-                              float* dst, void* workspace, size_t workspace_bytes, dvcStream stream) {
-    DVC_REQUIRE(guide && src && dst && workspace && planes > 0 && H > 0 && W > 0, "dvc_fgs_filter: bad argument");
+extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_guides, int32_t planes_per_guide,
+                              int32_t H, int32_t W, float lambda, float sigma_color, int32_t num_iter,
+                              float lambda_attenuation, float* dst, void* workspace, size_t workspace_bytes,
+                              dvcStream stream) {
+    DVC_REQUIRE(guide && src && dst && workspace && n_guides > 0 && planes_per_guide > 0 && H > 0 && W > 0,
+                "dvc_fgs_filter: bad argument");
+    const int planes = n_guides * planes_per_guide;
     DVC_REQUIRE(num_iter >= 1 && num_iter <= 8 && sigma_color > 0.f && lambda >= 0.f, "dvc_fgs_filter: bad parameters");
-    DVC_REQUIRE(workspace_bytes >= dvc_fgs_workspace_bytes(H, W, planes), "dvc_fgs_filter: workspace too small");
+    DVC_REQUIRE(workspace_bytes >= dvc_fgs_workspace_bytes(H, W, n_guides, planes_per_guide),
+                "dvc_fgs_filter: workspace too small");
     DVC_REQUIRE((long)H * W < (1L << 30), "dvc_fgs_filter: image too large");
     hipStream_t s = (hipStream_t)stream;
     const size_t HW = (size_t)H * W;
     float* wv = reinterpret_cast<float*>(workspace);
-    float* wh_t = wv + HW;
-    float* tr = wh_t + HW;
+    float* wh_t = wv + n_guides * HW;
+    float* tr = wh_t + n_guides * HW;
     float* cp = tr + planes * HW;
     float* dp = cp + planes * HW;
-    hipLaunchKernelGGL(fgs_weights_kernel, dim3(cdiv((int)HW, 1024)), dim3(256), 0, s, guide, H, W,
+    hipLaunchKernelGGL(fgs_weights_kernel, dim3(cdiv((int)HW, 1024), n_guides), dim3(256), 0, s, guide, H, W,
                        1.0f / sigma_color, wv, wh_t);
     DVC_CHECK_LAUNCH("dvc_fgs_filter(weights)");
     if (dst != src) {
@@ -192,10 +199,12 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t pl
         // rows: transpose -> lines are the W columns of the transposed [W][H] image, length... each ROW of the
         // image is a line of length W: in the transposed image [W][H] it runs along axis 0 with M = H lines
         hipLaunchKernelGGL(transpose_kernel, tgrid_fwd, dim3(256), 0, s, dst, H, W, tr);
-        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(H, 64), planes), dim3(64), 0, s, tr, wh_t, W, H, lam_f, cp, dp);
+        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(H, 64), planes), dim3(64), 0, s, tr, wh_t, W, H,
+                           planes_per_guide, lam_f, cp, dp);
         hipLaunchKernelGGL(transpose_kernel, tgrid_bwd, dim3(256), 0, s, tr, W, H, dst);
         // columns
-        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(W, 64), planes), dim3(64), 0, s, dst, wv, H, W, lam_f, cp, dp);
+        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(W, 64), planes), dim3(64), 0, s, dst, wv, H, W,
+                           planes_per_guide, lam_f, cp, dp);
         DVC_CHECK_LAUNCH("dvc_fgs_filter(solve)");
         lam_f = lam_f * lambda_attenuation;
     }

@@ -50,8 +50,8 @@ SIGNATURES = {
     "dvc_pack_color_input": (ctypes.c_int, [_VP, _VP, _VP, _VP, c_i32, c_i32, _VP, _VP]),
     "dvc_upsample_bilinear2x": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP]),
     "dvc_lum_guide_u8": (ctypes.c_int, [_VP, c_i64, _VP, _VP]),
-    "dvc_fgs_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32]),
-    "dvc_fgs_filter": (ctypes.c_int, [_VP, _VP, c_i32, c_i32, c_i32, ctypes.c_float, ctypes.c_float, c_i32,
+    "dvc_fgs_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32]),
+    "dvc_fgs_filter": (ctypes.c_int, [_VP, _VP, c_i32, c_i32, c_i32, c_i32, ctypes.c_float, ctypes.c_float, c_i32,
                                       ctypes.c_float, _VP, _VP, ctypes.c_size_t, _VP]),
     "dvc_lab2rgb_u8": (ctypes.c_int, [_VP, _VP, c_i32, c_i32, _VP, _VP]),
     "dvc_rgb8_to_lab": (ctypes.c_int, [_VP, c_i32, c_i32, _VP, _VP]),

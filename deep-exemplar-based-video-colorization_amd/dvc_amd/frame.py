@@ -173,11 +173,12 @@ class ClipColorizer:
         return outs
 
     def clip_rgb(self, frames_lab_large, wls_filter_on=True, lambda_value=500, sigma_color=4, frame_propagate=False,
-                 lookahead=2):
+                 lookahead=2, tail_batch=4):
         """The device-side part of the whole per-frame loop of test.py:68-116: full-resolution Lab frames
         (what `transform(...)` yields, test.py:70) -> x0.5 bilinear -> frame_colorization recurrence -> x2
         bilinear * 1.25 -> WLS filter -> 8-bit RGB (H x W x 3 uint8 device tensors, one per frame).
-        The tail of frame t runs on its own low-priority stream, off the recurrence's critical path."""
+        The tails run on their own low-priority stream, off the recurrence's critical path, `tail_batch`
+        frames per set of launches (the filter is a latency chain: more frames = more lines in flight)."""
         from . import tail
         frames_lab_large = [f.detach().contiguous().float() for f in frames_lab_large]
         small = [tail.downsample_half(f) for f in frames_lab_large]
@@ -187,14 +188,26 @@ class ClipColorizer:
         ts = self._tail_stream
         ts.wait_stream(caller)
         rgbs = [None] * len(small)
+        pending = []
+
+        def flush():
+            ev = torch.cuda.Event()
+            ev.record()                         # on the stream that produced the newest `ab`
+            ts.wait_event(ev)
+            idx = [t for t, _ in pending]
+            for _, ab in pending:
+                ab.record_stream(ts)
+            with torch.cuda.stream(ts):
+                out, _ = tail.frames_tail([frames_lab_large[t] for t in idx], [ab for _, ab in pending],
+                                          wls_filter_on, lambda_value, sigma_color)
+            for t, r in zip(idx, out):
+                rgbs[t] = r
+            pending.clear()
 
         def on_frame(t, IA_lab, ab):
-            ev = torch.cuda.Event()
-            ev.record()                         # on the stream that produced `ab`
-            ab.record_stream(ts)
-            ts.wait_event(ev)
-            with torch.cuda.stream(ts):
-                rgbs[t], _ = tail.frame_tail(frames_lab_large[t], ab, wls_filter_on, lambda_value, sigma_color)
+            pending.append((t, ab))
+            if len(pending) >= tail_batch or t == len(small) - 1:
+                flush()
 
         self.clip(small, frame_propagate=frame_propagate, lookahead=lookahead, on_frame=on_frame)
         caller.wait_stream(ts)

@@ -40,18 +40,22 @@ def luminance_guide_u8(L_centered):
 
 
 def fgs_filter(guide_u8, src, lambda_value=500.0, sigma_color=4.0, num_iter=3, lambda_attenuation=0.25):
-    """cv2.ximgproc.createFastGlobalSmootherFilter(guide, lambda, sigma_color).filter(plane) for every plane of
-    `src` [planes, H, W] (test.py:107-111); guide_u8: [H, W] uint8."""
+    """cv2.ximgproc.createFastGlobalSmootherFilter(guide, lambda, sigma_color).filter(plane) (test.py:107-111).
+    One frame: guide_u8 [H, W] uint8, src [planes, H, W].  Several frames in one call: guide_u8 [G, H, W],
+    src [G, planes, H, W] (every frame's planes are filtered with that frame's guide)."""
     lib = _lib.load()
     _need(src, "src")
     if guide_u8.dtype != torch.uint8 or not guide_u8.is_cuda or not guide_u8.is_contiguous():
         raise RuntimeError("dvc_amd: `guide` must be a contiguous uint8 ROCm tensor")
-    planes, H, W = src.shape
-    if tuple(guide_u8.shape) != (H, W):
-        raise RuntimeError(f"dvc_amd: guide shape {tuple(guide_u8.shape)} != {(H, W)}")
+    batched = guide_u8.dim() == 3
+    G = guide_u8.shape[0] if batched else 1
+    ppg = src.shape[1] if batched else src.shape[0]
+    H, W = src.shape[-2:]
+    if tuple(guide_u8.shape[-2:]) != (H, W) or (batched and (src.dim() != 4 or src.shape[0] != G)):
+        raise RuntimeError(f"dvc_amd: guide {tuple(guide_u8.shape)} does not fit src {tuple(src.shape)}")
     dst = torch.empty_like(src)
-    ws = _workspace(src.device, lib.dvc_fgs_workspace_bytes(H, W, planes), "fgs")
-    _lib.check(lib.dvc_fgs_filter(ctypes.c_void_p(guide_u8.data_ptr()), _p(src), planes, H, W, float(lambda_value),
+    ws = _workspace(src.device, lib.dvc_fgs_workspace_bytes(H, W, G, ppg), "fgs")
+    _lib.check(lib.dvc_fgs_filter(ctypes.c_void_p(guide_u8.data_ptr()), _p(src), G, ppg, H, W, float(lambda_value),
                                   float(sigma_color), int(num_iter), float(lambda_attenuation), _p(dst),
                                   ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "dvc_fgs_filter")
     return dst
@@ -95,3 +99,14 @@ def frame_tail(IA_lab_large, I_current_ab_predict, wls_filter_on=True, lambda_va
         curr_predict = fgs_filter(guide_image, curr_predict[0], lambda_value, sigma_color).unsqueeze(0)
     IA_predict_rgb = lab_to_rgb8(curr_bs_l[0, 0], curr_predict[0])
     return IA_predict_rgb, curr_predict
+
+
+def frames_tail(IA_lab_large_list, ab_list, wls_filter_on=True, lambda_value=500, sigma_color=4):
+    """`frame_tail` for several frames at once (same results): the filter of G frames is one set of launches
+    with G x more independent lines in flight, which is what this latency-bound filter lacks."""
+    G = len(ab_list)
+    L = torch.cat([f[:, 0:1] for f in IA_lab_large_list], dim=0).contiguous()          # [G,1,2H,2W]
+    cur = upsample_ab(torch.cat([a.detach().float() for a in ab_list], dim=0).contiguous())   # [G,2,2H,2W]
+    if wls_filter_on:
+        cur = fgs_filter(luminance_guide_u8(L[:, 0]), cur, lambda_value, sigma_color)
+    return [lab_to_rgb8(L[g, 0], cur[g]) for g in range(G)], cur

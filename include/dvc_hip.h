@@ -171,11 +171,13 @@ int dvc_lum_guide_u8(const float* L_centered, int64_t n, uint8_t* guide, dvcStre
 /* cv2.ximgproc.createFastGlobalSmootherFilter(guide, lambda, sigma_color).filter(src) on `planes` float planes
  * (test.py:107-111): Min et al. 2014, Alg. 1 — num_iter x {row solve, column solve}, lambda_t = 1.5 * 4^(T-t) /
  * (4^T - 1) * lambda, weights exp(-|dg| / sigma_color).  OpenCV's defaults: num_iter 3, attenuation 0.25.
- * dst may be src.  Parity unpinned (opencv-contrib is absent from the build image; see oracle/tail_oracle.py). */
-size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t planes);
-int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t planes, int32_t H, int32_t W, float lambda,
-                   float sigma_color, int32_t num_iter, float lambda_attenuation, float* dst, void* workspace,
-                   size_t workspace_bytes, dvcStream stream);
+ * Several frames (guides) are filtered by one call: planes g*planes_per_guide.. use guide g.  dst may be src.
+ * Parity unpinned (opencv-contrib is absent from the build image; see oracle/tail_oracle.py). */
+size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t n_guides, int32_t planes_per_guide);
+int dvc_fgs_filter(const uint8_t* guide /* [n_guides][H][W] */, const float* src /* [n_guides*planes_per_guide][H][W] */,
+                   int32_t n_guides, int32_t planes_per_guide, int32_t H, int32_t W, float lambda, float sigma_color,
+                   int32_t num_iter, float lambda_attenuation, float* dst, void* workspace, size_t workspace_bytes,
+                   dvcStream stream);
 /* batch_lab2rgb_transpose_mc for one image (utils/util.py:134-151): Lab (L centred) -> skimage lab2rgb (float64)
  * -> clip -> *255 -> uint8, H x W x 3.  ab = [2][H][W].  Parity unpinned (skimage absent). */
 int dvc_lab2rgb_u8(const float* L_centered, const float* ab, int32_t H, int32_t W, uint8_t* rgb_hwc,

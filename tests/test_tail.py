@@ -139,6 +139,13 @@ def test_gpu_frame_tail_end_to_end():
     assert np.array_equal(cur2.cpu().numpy(), T.upsample_ab(ab.numpy()))
     with pytest.raises(RuntimeError):
         tail.frame_tail(lab_large, ab)          # CPU tensors: no fallback
+    # several frames in one call == frame by frame
+    labs = [lab_large.cuda(), (lab_large * 0.5).cuda(), (lab_large * -0.3).cuda()]
+    abs_ = [ab.cuda(), (ab * 0.7).cuda(), (ab + 3).cuda()]
+    many, _ = tail.frames_tail(labs, abs_)
+    for lg, a, r in zip(labs, abs_, many):
+        one, _ = tail.frame_tail(lg, a)
+        assert torch.equal(one, r)
 
 
 @pytest.mark.gpu

@@ -31,3 +31,30 @@ for name, fn in (("whole tail", lambda: tail.frame_tail(lab, ab)),
 t0 = time.perf_counter()
 T.frame_tail(L.numpy(), ab.cpu().numpy())
 print(f"CPU oracle (numpy, 1 core): {(time.perf_counter() - t0) * 1e3:.0f} ms per frame")
+
+# ---- whole device-side loop: full-resolution Lab frames in -> 8-bit RGB out (ClipColorizer.clip_rgb)
+import bench  # noqa: E402
+from dvc_amd import ops, synth  # noqa: E402
+from dvc_amd.frame import ClipColorizer  # noqa: E402
+
+dev = torch.device("cuda")
+nets, _ = bench.build_nets(dev)
+ops.set_autotune(True)
+cc = ClipColorizer(*nets, temperature=1e-10)
+cc.set_exemplar(tail.downsample_half(synth.synth_lab(synth.EXEMPLAR_SEED, 2 * H, 2 * W).to(dev)))
+K = 30
+large = [synth.synth_lab(synth.FRAME_SEED0 + i, 2 * H, 2 * W).to(dev) for i in range(K)]
+small = [tail.downsample_half(f) for f in large]
+for f in small[:4]:
+    cc.frame(f, torch.zeros_like(f))          # autotune, sequentially
+cc.clip(small[:4])
+cc.clip_rgb(large[:4])
+torch.cuda.synchronize()
+for name, fn in (("clip (network resolution in, ab out)", lambda: cc.clip(small)),
+                 ("clip_rgb (432x768 Lab in, RGB8 out, WLS on)", lambda: cc.clip_rgb(large)),
+                 ("clip_rgb, WLS off", lambda: cc.clip_rgb(large, wls_filter_on=False))):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    print(f"{name}: {K / (time.perf_counter() - t0):.1f} frames/s")
