@@ -40,7 +40,7 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 // Works for any block size that is a multiple of 64 up to 1024; every thread returns the plane's
 // (scale, shift) = (rstd * chan_scale, -mean * scale).
 __device__ __forceinline__ void plane_stats(const float* __restrict__ xp, int HW, float eps, float cs,
-                                            double* red /* [34] */, float* sc_out, float* sh_out) {
+                                            double* red /* [36] */, float* sc_out, float* sh_out) {
     const int tid = threadIdx.x, nt = blockDim.x;
     double s = 0.0, q = 0.0;
     const int HW4 = ((reinterpret_cast<uintptr_t>(xp) & 15) == 0) ? (HW & ~3) : 0;
@@ -76,6 +76,8 @@ __device__ __forceinline__ void plane_stats(const float* __restrict__ xp, int HW
         const double sc = rstd * (double)cs;
         red[32] = sc;
         red[33] = -mean * sc;
+        red[34] = mean;
+        red[35] = rstd;
     }
     __syncthreads();
     *sc_out = (float)red[32];
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(1024) void instnorm_stats_kernel(const float* __res
                                                               const float* __restrict__ chan_scale,
                                                               float* __restrict__ scale,
                                                               float* __restrict__ shift) {
-    __shared__ double red[34];
+    __shared__ double red[36];
     const int p = blockIdx.x;  // n*C + c
     const int n = p / C, c = p - n * C;
     float sc, sh;
@@ -122,8 +124,10 @@ __global__ __launch_bounds__(1024) void instnorm_apply_kernel(const float* __res
                                                               int C, int H, int W, int up, int sub, int rpad,
                                                               long x_bs, long res_bs, long y_bs,
                                                               float* __restrict__ y, float* __restrict__ scale,
-                                                              float* __restrict__ shift) {
-    __shared__ double red[34];
+                                                              float* __restrict__ shift,
+                                                              const float* __restrict__ chan_scale2, int sub2,
+                                                              long y2_bs, float* __restrict__ y2) {
+    __shared__ double red[36];
     const int p = blockIdx.x;  // n*C + c
     const int n = p / C, c = p - n * C;
     const float* xp = x + (long)n * x_bs + (long)c * H * W;
@@ -132,6 +136,16 @@ __global__ __launch_bounds__(1024) void instnorm_apply_kernel(const float* __res
     if (threadIdx.x == 0 && scale) {
         scale[p] = sc;
         shift[p] = sh;
+    }
+    if (y2) {  // second consumer of the same statistics: y2 = x * (rstd * chan_scale2) + shift, stride sub2
+        const double sc2d = red[35] * (chan_scale2 ? (double)chan_scale2[c] : 1.0);
+        const float sc2 = (float)sc2d, sh2 = (float)(-red[34] * sc2d);
+        const int OH2 = sub2 == 2 ? (H + 1) / 2 : H, OW2 = sub2 == 2 ? (W + 1) / 2 : W;
+        float* y2p = y2 + (long)n * y2_bs + (long)c * OH2 * OW2;
+        for (int i = threadIdx.x; i < OH2 * OW2; i += blockDim.x) {
+            const int oy = i / OW2, ox = i - oy * OW2;
+            y2p[i] = xp[(oy * sub2) * W + ox * sub2] * sc2 + sh2;
+        }
     }
     const bool has_act = slope_ptr != nullptr;
     const float slope = has_act ? *slope_ptr : 1.f;
@@ -182,8 +196,11 @@ extern "C" int dvc_instnorm_apply(const float* x, const float* residual, const f
                                   const float* chan_scale, float eps, int32_t N, int32_t C, int32_t H,
                                   int32_t W, int32_t up, int32_t sub, int32_t rpad, int64_t x_batch_stride,
                                   int64_t res_batch_stride, int64_t y_batch_stride, float* y,
-                                  float* scale_out, float* shift_out, dvcStream stream) {
+                                  float* scale_out, float* shift_out, const float* chan_scale2, int32_t sub2,
+                                  float* y2, dvcStream stream) {
     DVC_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0, "dvc_instnorm_apply: bad argument");
+    DVC_REQUIRE(!y2 || ((sub2 == 1 || sub2 == 2) && y2 != x && y2 != y), "dvc_instnorm_apply: bad second output");
+    DVC_REQUIRE(!(y2 && x == y), "dvc_instnorm_apply: a second output excludes in-place operation");
     DVC_REQUIRE(up >= 1 && up <= 4 && (sub == 1 || sub == 2) && rpad >= 0 && !(up != 1 && sub != 1),
                 "dvc_instnorm_apply: bad up/sub/rpad");
     DVC_REQUIRE(!(residual && (up != 1 || sub != 1)), "dvc_instnorm_apply: residual requires up == sub == 1");
@@ -196,7 +213,8 @@ extern "C" int dvc_instnorm_apply(const float* x, const float* residual, const f
     long ybs = y_batch_stride ? y_batch_stride : (long)C * OH * OW;
     hipLaunchKernelGGL(instnorm_apply_kernel, dim3(N * C), dim3(instnorm_block(H * W)), 0, (hipStream_t)stream,
                        x, residual, slope_ptr, chan_scale, eps, C, H, W, up, sub, rpad, xbs, rbs, ybs, y,
-                       scale_out, shift_out);
+                       scale_out, shift_out, chan_scale2, y2 ? sub2 : 1,
+                       (long)C * (sub2 == 2 ? (H + 1) / 2 : H) * (sub2 == 2 ? (W + 1) / 2 : W), y2);
     DVC_CHECK_LAUNCH("dvc_instnorm_apply");
     return 0;
 }

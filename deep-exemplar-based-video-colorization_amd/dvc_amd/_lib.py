@@ -39,7 +39,7 @@ SIGNATURES = {
     "dvc_affine_act": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                       c_i64, c_i64, c_i64, _VP, _VP]),
     "dvc_instnorm_apply": (ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i32, c_i32, c_i32,
-                                          c_i32, c_i32, c_i64, c_i64, c_i64, _VP, _VP, _VP, _VP]),
+                                          c_i32, c_i32, c_i64, c_i64, c_i64, _VP, _VP, _VP, _VP, c_i32, _VP, _VP]),
     "dvc_maxpool2x2": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),
     "dvc_avgpool2x2": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),
     "dvc_avgpool4x4": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),

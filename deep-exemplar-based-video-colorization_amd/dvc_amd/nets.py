@@ -313,15 +313,24 @@ class ColorVidNet(nn.Module):
         acts = {"x": x}
         normed = {}
 
+        # activations that are normalised for two consumers (skip convolution: plain; next block: * `_ss`
+        # weight, stride 2) get both tensors from one launch
+        both = {c["src"]: c["ss"] for c in arch.CVN_CONVS if c["pre"] == "norm_ss"}
+        both = {k: v for k, v in both.items() if any(c["src"] == k and c["pre"] in ("norm", "up") for c in arch.CVN_CONVS)}
+
         def norm_of(src, ss_key=None):
             """InstanceNorm2d(src) [* the depthwise `_ss` weight, stride 2] as a tensor (ColorVidNet.py:85-94,12)."""
             k = (src, ss_key)
             if k not in normed:
-                cs = None
-                if ss_key is not None:
-                    ssw = self._mod(ss_key).weight
-                    cs = self._cache.get(ss_key, ssw, lambda w: w.detach().reshape(-1).contiguous())
-                normed[k] = ops.instnorm_apply(acts[src], eps=1e-5, chan_scale=cs, sub=2 if ss_key else 1)
+                def ss_weight(key):
+                    return self._cache.get(key, self._mod(key).weight, lambda w: w.detach().reshape(-1).contiguous())
+                if src in both:
+                    normed[(src, None)], normed[(src, both[src])] = ops.instnorm_apply(
+                        acts[src], eps=1e-5, second=(ss_weight(both[src]), 2))
+                else:
+                    normed[k] = ops.instnorm_apply(acts[src], eps=1e-5,
+                                                   chan_scale=ss_weight(ss_key) if ss_key else None,
+                                                   sub=2 if ss_key else 1)
             return normed[k]
 
         act_map = {"relu": ops.ACT_RELU, "none": ops.ACT_NONE, "leaky": ops.ACT_LEAKY}

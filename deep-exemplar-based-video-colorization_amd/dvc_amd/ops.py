@@ -224,9 +224,11 @@ def affine_act(x, scale, shift, *, residual=None, slope_t=None, up=1, rpad=0, ou
 
 
 def instnorm_apply(x, *, eps=1e-5, chan_scale=None, residual=None, slope_t=None, up=1, sub=1, rpad=0, out=None,
-                   out_batch_stride=0):
+                   out_batch_stride=0, second=None):
     """InstanceNorm2d (no affine, biased variance) + optional depthwise scale / skip-add / PReLU / nearest
-    upsample / stride-2 subsample / replicate row pad, in one launch; `out=x` normalises in place."""
+    upsample / stride-2 subsample / replicate row pad, in one launch; `out=x` normalises in place.
+    `second=(chan_scale2, sub2)` also returns InstanceNorm(x) * chan_scale2 at stride sub2 (same statistics,
+    same launch): the call then returns (y, y2)."""
     lib = _lib.load()
     for t, nm in ((x, "x"), (chan_scale, "chan_scale"), (residual, "residual"), (slope_t, "slope")):
         _need(t, nm)
@@ -234,10 +236,17 @@ def instnorm_apply(x, *, eps=1e-5, chan_scale=None, residual=None, slope_t=None,
     VH, VW = ((H + 1) // 2, (W + 1) // 2) if sub == 2 else (H * up, W * up)
     if out is None:
         out = torch.empty((N, C, VH + 2 * rpad, VW), device=x.device, dtype=torch.float32)
+    cs2, sub2, y2 = None, 1, None
+    if second is not None:
+        cs2, sub2 = second
+        _need(cs2, "chan_scale2")
+        y2 = torch.empty((N, C, (H + 1) // 2, (W + 1) // 2) if sub2 == 2 else (N, C, H, W), device=x.device,
+                         dtype=torch.float32)
     _lib.check(lib.dvc_instnorm_apply(_p(x), _p(residual), _p(slope_t), _p(chan_scale), float(eps), N, C, H, W, up,
-                                      sub, rpad, 0, 0, out_batch_stride, _p(out), None, None, _stream()),
+                                      sub, rpad, 0, 0, out_batch_stride, _p(out), None, None, _p(cs2), sub2,
+                                      _p(y2), _stream()),
                "dvc_instnorm_apply")
-    return out
+    return out if second is None else (out, y2)
 
 
 def _pool(fn_name, x, k):

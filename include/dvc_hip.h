@@ -125,12 +125,17 @@ int dvc_affine_act(const float* x, const float* scale, const float* shift, const
  * convs, ColorVidNet.py:12,16,21; chan_scale = their weights); up / rpad as in dvc_affine_act; up and sub
  * exclude each other.  y is [N][C][VH + 2*rpad][VW], VH = H*up or ceil(H/2); y may be x itself when
  * up == sub == 1 and rpad == 0.  scale_out / shift_out (both or neither; may be NULL) receive the affine.
+ * y2 (optional) is a second consumer's view of the same statistics: y2 = InstanceNorm(x) * chan_scale2 at stride
+ * sub2, contiguous [N][C][ceil(H/sub2)][ceil(W/sub2)] (ColorVidNet normalises conv1_2 / conv2_2 / conv3_3 once for
+ * the skip convolution and once, scaled and subsampled, for the next block).
  * The convolution that consumes y then needs no fused input transform and stages through LDS-DMA. */
 int dvc_instnorm_apply(const float* x, const float* residual /* or NULL */, const float* slope_ptr /* or NULL */,
                        const float* chan_scale /* [C] or NULL */, float eps, int32_t N, int32_t C, int32_t H,
                        int32_t W, int32_t up, int32_t sub, int32_t rpad, int64_t x_batch_stride,
                        int64_t res_batch_stride, int64_t y_batch_stride, float* y,
-                       float* scale_out, float* shift_out, dvcStream stream);
+                       float* scale_out, float* shift_out,
+                       const float* chan_scale2 /* [C] or NULL */, int32_t sub2, float* y2 /* or NULL */,
+                       dvcStream stream);
 
 /* nn.MaxPool2d(2,2) floor mode, NonlocalNet.py:237-255. planes = N*C. */
 int dvc_maxpool2x2(const float* x, int32_t planes, int32_t H, int32_t W, float* y, dvcStream stream);

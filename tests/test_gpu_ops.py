@@ -221,6 +221,9 @@ def test_instnorm_apply_fused(ops, shape):
     r = (ref * cs.double().cpu().view(1, C, 1, 1))[:, :, ::2, ::2]
     assert tuple(y.shape) == tuple(r.shape)
     assert (y.double().cpu() - r).abs().max().item() < 1e-5
+    # both consumers' tensors from one launch == the two separate launches, bit for bit
+    ya, yb = ops.instnorm_apply(x, second=(cs, 2))
+    assert torch.equal(ya, ops.instnorm_apply(x)) and torch.equal(yb, y)
     # IN + skip + PReLU, in place
     t = x.clone()
     y = ops.instnorm_apply(t, residual=res, slope_t=slope, out=t)
