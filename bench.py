@@ -40,8 +40,8 @@ PATH_FLOPS = 348.4e9                                     # minimal whole-path FL
 PEAK_F32_MFMA_TFLOPS = 157.3                             # MI355X_MICROARCH.md, fp32 matrix
 PEAK_HBM_GBS = 8000.0
 # PMC-measured HBM traffic of one corr_fwd_kernel launch at P=5184 (profiles/r01_pmc_summary.md):
-# 97.1 MB read + 3.7 MB written vs 10.76 MB compulsory (phi is re-streamed through the per-XCD L2s)
-CORR_TRAFFIC_BYTES = 100.8e6
+# 102.2 MB read + 3.7 MB written vs 10.76 MB compulsory (phi is re-streamed through the per-XCD L2s)
+CORR_TRAFFIC_BYTES = 105.9e6
 CORR_TRAFFIC_SOURCE = "profiles/r01_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
 
 
