@@ -60,7 +60,7 @@ extern "C" int dvc_lum_guide_u8(const float* L_centered, int64_t n, uint8_t* gui
 // T iterations of { 1-D WLS solve along every row ; along every column } with
 //   lambda_t = 1.5 * 4^(T-t) / (4^T - 1) * lambda,   w(p,q) = exp(-|g_p - g_q| / sigma_color)  (8-bit guide),
 // each 1-D solve a tridiagonal system (a_x = -lambda w(x-1,x), c_x = -lambda w(x,x+1), b_x = 1 - a_x - c_x),
-// Thomas algorithm in float32.
+// Thomas algorithm in float32 (with the reciprocal of the pivot, see fgs_coeff_kernel).
 // Mapping: one thread per LINE; consecutive threads own consecutive lines and march along the other axis, so
 // every load / store of the column solve is a coalesced row.  The row solve runs on the transposed image (a
 // 32x32 LDS-tile transpose before and after).  The sweeps are latency chains (one divide + two fma per
@@ -97,74 +97,111 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
         if (bx + r < W && by + tx < H) yp[(long)(bx + r) * H + by + tx] = t[tx][r];
 }
 
-// solve (I + lambda A) u = f along axis 0 of f [planes][L][M] (L = line length, M = number of lines), in place;
-// w [L][M] = weight between element l and l+1 of line m; cp / dp: [planes][L][M] scratch.
+// The tridiagonal systems depend on the guide and lambda only, so their elimination coefficients are computed
+// once per (direction, iteration) and shared by all planes of a guide:
+//   m_l = b_l - a_l c'_{l-1},  inv_l = 1 / m_l,  c'_l = c_l inv_l            (one divide per element, here)
+//   d'_l = (f_l - a_l d'_{l-1}) inv_l = fma(-(a_l inv_l), d'_{l-1}, f_l inv_l) (one dependent fma per element, below)
+// Both kernels: one thread per line, FGS_U elements fetched ahead of the dependent chain.
 #define FGS_U 16
-__global__ __launch_bounds__(64) void fgs_solve_kernel(float* __restrict__ f, const float* __restrict__ w, int L,
-                                                       int M, int planes_per_guide, float lambda,
-                                                       float* __restrict__ cp, float* __restrict__ dp) {
+__global__ __launch_bounds__(64) void fgs_coeff_kernel(const float* __restrict__ w, int L, int M, float lambda,
+                                                       float* __restrict__ cp, float* __restrict__ inv) {
     const int m = blockIdx.x * 64 + threadIdx.x;
     if (m >= M) return;
-    float* fp = f + (long)blockIdx.y * L * M + m;
-    float* cpp = cp + (long)blockIdx.y * L * M + m;
-    float* dpp = dp + (long)blockIdx.y * L * M + m;
-    const float* wp = w + (long)(blockIdx.y / planes_per_guide) * L * M + m;
-    // forward elimination.  The loads do not depend on the recurrence: fetch FGS_U elements ahead, then run
-    // the FGS_U dependent steps from registers (otherwise every step exposes a global-load latency)
-    float a = 0.f;                                   // a_0 = 0
+    const long off = (long)blockIdx.y * L * M + m;       // blockIdx.y = guide
+    const float* wp = w + off;
+    float* cpp = cp + off;
+    float* ivp = inv + off;
+    float a = 0.f;
     float c = L > 1 ? -lambda * wp[0] : 0.f;
-    float b = 1.f - a - c;
-    float cprev = c / b, dprev = fp[0] / b;
+    float iv = 1.f / (1.f - a - c);
+    float cprev = c * iv;
     cpp[0] = cprev;
-    dpp[0] = dprev;
-    for (int l0 = 1; l0 < L; l0 += FGS_U) {
-        float wk[FGS_U], fk[FGS_U];
+    ivp[0] = iv;
+    int l0 = 1;
+    for (; l0 + FGS_U < L; l0 += FGS_U) {            // full blocks (never contain the last element): no conditions
+        float wk[FGS_U];
+#pragma unroll
+        for (int k = 0; k < FGS_U; ++k) wk[k] = wp[(long)(l0 + k) * M];
 #pragma unroll
         for (int k = 0; k < FGS_U; ++k) {
-            const int l = l0 + k;
-            wk[k] = l + 1 < L ? wp[(long)l * M] : 0.f;
-            fk[k] = l < L ? fp[(long)l * M] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < FGS_U; ++k) {
-            const int l = l0 + k;
-            if (l < L) {
-                a = c;                               // a_l = -lambda w(l-1,l) = c_{l-1}
-                c = -lambda * wk[k];                 // (0 at the end of the line)
-                b = 1.f - a - c;
-                const float mden = b - a * cprev;
-                cprev = c / mden;
-                dprev = (fk[k] - a * dprev) / mden;
-                cpp[(long)l * M] = cprev;
-                dpp[(long)l * M] = dprev;
-            }
+            a = c;                                       // a_l = -lambda w(l-1,l) = c_{l-1}
+            c = -lambda * wk[k];
+            iv = 1.f / ((1.f - a - c) - a * cprev);
+            cprev = c * iv;
+            cpp[(long)(l0 + k) * M] = cprev;
+            ivp[(long)(l0 + k) * M] = iv;
         }
     }
-    // back substitution, same prefetch scheme
+    for (int l = l0; l < L; ++l) {
+        a = c;
+        c = l + 1 < L ? -lambda * wp[(long)l * M] : 0.f;
+        iv = 1.f / ((1.f - a - c) - a * cprev);
+        cprev = c * iv;
+        cpp[(long)l * M] = cprev;
+        ivp[(long)l * M] = iv;
+    }
+}
+
+// solve along axis 0 of f [planes][L][M] in place (planes g*ppg .. use guide g's coefficients); dp: scratch
+__global__ __launch_bounds__(64) void fgs_solve_kernel(float* __restrict__ f, const float* __restrict__ w,
+                                                       const float* __restrict__ cp, const float* __restrict__ inv,
+                                                       int L, int M, int planes_per_guide, float lambda,
+                                                       float* __restrict__ dp) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= M) return;
+    const long goff = (long)(blockIdx.y / planes_per_guide) * L * M + m;
+    float* fp = f + (long)blockIdx.y * L * M + m;
+    float* dpp = dp + (long)blockIdx.y * L * M + m;
+    const float* wp = w + goff;
+    const float* cpp = cp + goff;
+    const float* ivp = inv + goff;
+    float dprev = fp[0] * ivp[0];
+    dpp[0] = dprev;
+    int l0 = 1;
+    for (; l0 + FGS_U <= L; l0 += FGS_U) {           // full blocks: no conditions, 48 independent loads in flight
+        float ak[FGS_U], fk[FGS_U];
+#pragma unroll
+        for (int k = 0; k < FGS_U; ++k) {
+            const float iv = ivp[(long)(l0 + k) * M];
+            ak[k] = lambda * wp[(long)(l0 + k - 1) * M] * iv;              // -(a_l inv_l), a_l = -lambda w(l-1,l)
+            fk[k] = fp[(long)(l0 + k) * M] * iv;
+        }
+#pragma unroll
+        for (int k = 0; k < FGS_U; ++k) {
+            dprev = fmaf(ak[k], dprev, fk[k]);
+            dpp[(long)(l0 + k) * M] = dprev;
+        }
+    }
+    for (int l = l0; l < L; ++l) {
+        const float iv = ivp[(long)l * M];
+        dprev = fmaf(lambda * wp[(long)(l - 1) * M] * iv, dprev, fp[(long)l * M] * iv);
+        dpp[(long)l * M] = dprev;
+    }
     float u = dprev;
     fp[(long)(L - 1) * M] = u;
-    for (int l0 = L - 2; l0 >= 0; l0 -= FGS_U) {
+    int l1 = L - 2;
+    for (; l1 - (FGS_U - 1) >= 0; l1 -= FGS_U) {
         float ck[FGS_U], dk[FGS_U];
 #pragma unroll
         for (int k = 0; k < FGS_U; ++k) {
-            const int l = l0 - k;
-            ck[k] = l >= 0 ? cpp[(long)l * M] : 0.f;
-            dk[k] = l >= 0 ? dpp[(long)l * M] : 0.f;
+            ck[k] = cpp[(long)(l1 - k) * M];
+            dk[k] = dpp[(long)(l1 - k) * M];
         }
 #pragma unroll
         for (int k = 0; k < FGS_U; ++k) {
-            const int l = l0 - k;
-            if (l >= 0) {
-                u = dk[k] - ck[k] * u;
-                fp[(long)l * M] = u;
-            }
+            u = fmaf(-ck[k], u, dk[k]);
+            fp[(long)(l1 - k) * M] = u;
         }
+    }
+    for (int l = l1; l >= 0; --l) {
+        u = fmaf(-cpp[(long)l * M], u, dpp[(long)l * M]);
+        fp[(long)l * M] = u;
     }
 }
 
 extern "C" size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t n_guides, int32_t planes_per_guide) {
-    // per guide: wv + wh_t; per plane: transposed image + cp + dp
-    return sizeof(float) * ((size_t)2 * n_guides * H * W + (size_t)3 * n_guides * planes_per_guide * H * W);
+    // per guide: wv, wh_t and (c', 1/m) of the row and of the column system; per plane: transposed image + d'
+    return sizeof(float) * ((size_t)6 * n_guides * H * W + (size_t)2 * n_guides * planes_per_guide * H * W);
 }
 
 extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_guides, int32_t planes_per_guide,
@@ -179,12 +216,15 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
                 "dvc_fgs_filter: workspace too small");
     DVC_REQUIRE((long)H * W < (1L << 30), "dvc_fgs_filter: image too large");
     hipStream_t s = (hipStream_t)stream;
-    const size_t HW = (size_t)H * W;
+    const size_t HW = (size_t)H * W, GHW = (size_t)n_guides * HW;
     float* wv = reinterpret_cast<float*>(workspace);
-    float* wh_t = wv + n_guides * HW;
-    float* tr = wh_t + n_guides * HW;
-    float* cp = tr + planes * HW;
-    float* dp = cp + planes * HW;
+    float* wh_t = wv + GHW;
+    float* cp_r = wh_t + GHW;   // row system (lines of length W, on the transposed image)
+    float* iv_r = cp_r + GHW;
+    float* cp_c = iv_r + GHW;   // column system
+    float* iv_c = cp_c + GHW;
+    float* tr = iv_c + GHW;
+    float* dp = tr + planes * HW;
     hipLaunchKernelGGL(fgs_weights_kernel, dim3(cdiv((int)HW, 1024), n_guides), dim3(256), 0, s, guide, H, W,
                        1.0f / sigma_color, wv, wh_t);
     DVC_CHECK_LAUNCH("dvc_fgs_filter(weights)");
@@ -196,15 +236,16 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
     float lam_f = (float)lam;
     const dim3 tgrid_fwd(cdiv(W, 32), cdiv(H, 32), planes), tgrid_bwd(cdiv(H, 32), cdiv(W, 32), planes);
     for (int it = 0; it < num_iter; ++it) {
-        // rows: transpose -> lines are the W columns of the transposed [W][H] image, length... each ROW of the
-        // image is a line of length W: in the transposed image [W][H] it runs along axis 0 with M = H lines
+        hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(H, 64), n_guides), dim3(64), 0, s, wh_t, W, H, lam_f, cp_r, iv_r);
+        hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(W, 64), n_guides), dim3(64), 0, s, wv, H, W, lam_f, cp_c, iv_c);
+        // rows: every image row is a line of length W; in the transposed image [W][H] it runs along axis 0
         hipLaunchKernelGGL(transpose_kernel, tgrid_fwd, dim3(256), 0, s, dst, H, W, tr);
-        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(H, 64), planes), dim3(64), 0, s, tr, wh_t, W, H,
-                           planes_per_guide, lam_f, cp, dp);
+        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(H, 64), planes), dim3(64), 0, s, tr, wh_t, cp_r, iv_r, W, H,
+                           planes_per_guide, lam_f, dp);
         hipLaunchKernelGGL(transpose_kernel, tgrid_bwd, dim3(256), 0, s, tr, W, H, dst);
         // columns
-        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(W, 64), planes), dim3(64), 0, s, dst, wv, H, W,
-                           planes_per_guide, lam_f, cp, dp);
+        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(W, 64), planes), dim3(64), 0, s, dst, wv, cp_c, iv_c, H, W,
+                           planes_per_guide, lam_f, dp);
         DVC_CHECK_LAUNCH("dvc_fgs_filter(solve)");
         lam_f = lam_f * lambda_attenuation;
     }

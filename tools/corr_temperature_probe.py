@@ -1,0 +1,29 @@
+"""Timing of the fused correlation at the temperatures the reference uses: 1e-10 (test.py:94), 0.01 / 0.005
+(training), and with WTA_scale; P = 5184."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "deep-exemplar-based-video-colorization_amd"))
+import torch  # noqa: E402
+
+from dvc_amd import ops  # noqa: E402
+
+dev = torch.device("cuda")
+h, w = 54, 96
+P = h * w
+g = torch.Generator().manual_seed(1)
+th = ops.corr_prepare(torch.randn(1, 256, P, generator=g).to(dev))
+ph = ops.corr_prepare(torch.randn(1, 256, P, generator=g).to(dev))
+bl = torch.randn(1, 3, P, generator=g).to(dev)
+for T in (1e-10, 1e-6, 0.005, 0.01, 1.0):
+    for _ in range(3):
+        ops.corr_fwd(th, ph, bl, T, h, w)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.corr_fwd(th, ph, bl, T, h, w)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    print(f"T = {T:g}: {us:.0f} us  ({13.92e9 / us / 1e6:.1f} TFLOP/s, {13.92e9 / us / 1e6 / 157.3 * 100:.0f} % of fp32 MFMA peak)")
