@@ -55,6 +55,8 @@ SIGNATURES = {
                                       ctypes.c_float, _VP, _VP, ctypes.c_size_t, _VP]),
     "dvc_lab2rgb_u8": (ctypes.c_int, [_VP, _VP, c_i32, c_i32, _VP, _VP]),
     "dvc_rgb8_to_lab": (ctypes.c_int, [_VP, c_i32, c_i32, _VP, _VP]),
+    "dvc_center_pad_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
+    "dvc_center_pad": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, c_i32, _VP, _VP, ctypes.c_size_t, _VP]),
     "dvc_corr_prepare": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP]),
     "dvc_corr_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "dvc_corr_fwd": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_float, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,

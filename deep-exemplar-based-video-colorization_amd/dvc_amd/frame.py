@@ -214,3 +214,15 @@ class ClipColorizer:
         for x in rgbs:
             x.record_stream(caller)
         return rgbs
+
+    def colorize_video(self, frames_rgb8, reference_rgb8=None, image_size=(432, 768), wls_filter_on=True,
+                       lambda_value=500, sigma_color=4, frame_propagate=False):
+        """colorize_video of test.py:29-121 without its file I/O: 8-bit RGB device frames (any size) in, 8-bit RGB
+        colourised frames (image_size) out.  `image_size` is the size CenterPad produces (twice the network
+        resolution; the reference's --image_size is the network resolution and test.py:163 doubles it).
+        reference_rgb8=None with frame_propagate=True uses the first frame as the exemplar (test.py:50)."""
+        from . import tail
+        large = [tail.frame_ingest(f, image_size) for f in frames_rgb8]
+        ref_large = large[0] if (frame_propagate and reference_rgb8 is None) else tail.frame_ingest(reference_rgb8, image_size)
+        self.set_exemplar(tail.downsample_half(ref_large))                      # test.py:57-66
+        return self.clip_rgb(large, wls_filter_on, lambda_value, sigma_color, frame_propagate=frame_propagate)

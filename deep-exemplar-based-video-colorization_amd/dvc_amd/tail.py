@@ -85,6 +85,27 @@ def rgb8_to_lab(rgb_hwc):
     return lab
 
 
+def center_pad(rgb_hwc, image_size):
+    """CenterPad(image_size)(image) (utils/util_distortion.py:217-258) for an 8-bit H0 x W0 x 3 device image:
+    anti-aliased resize to the target width / height, centre crop -> uint8 [H, W, 3]."""
+    lib = _lib.load()
+    if rgb_hwc.dtype != torch.uint8 or not rgb_hwc.is_cuda or not rgb_hwc.is_contiguous() or rgb_hwc.shape[-1] != 3:
+        raise RuntimeError("dvc_amd: `rgb` must be a contiguous uint8 ROCm tensor [H, W, 3]")
+    H0, W0 = rgb_hwc.shape[:2]
+    H, W = int(image_size[0]), int(image_size[1])
+    out = torch.empty((H, W, 3), device=rgb_hwc.device, dtype=torch.uint8)
+    ws = _workspace(rgb_hwc.device, lib.dvc_center_pad_workspace_bytes(H0, W0), "ingest")
+    _lib.check(lib.dvc_center_pad(ctypes.c_void_p(rgb_hwc.data_ptr()), H0, W0, H, W, ctypes.c_void_p(out.data_ptr()),
+                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "dvc_center_pad")
+    return out
+
+
+def frame_ingest(rgb_hwc, image_size):
+    """transform(frame) of test.py:44-46 on the device: CenterPad -> (CenterCrop: identity) -> RGB2Lab -> ToTensor
+    -> Normalize; uint8 [H0, W0, 3] -> centred Lab [1, 3, H, W] (`IA_lab_large`, test.py:70)."""
+    return rgb8_to_lab(center_pad(rgb_hwc, image_size))
+
+
 def frame_tail(IA_lab_large, I_current_ab_predict, wls_filter_on=True, lambda_value=500, sigma_color=4):
     """test.py:98-116 for one frame (batch 1): returns (IA_predict_rgb uint8 [2H,2W,3] on the device,
     curr_predict[_filter] float32 [1,2,2H,2W]).  Names follow the reference."""

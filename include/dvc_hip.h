@@ -191,6 +191,13 @@ int dvc_lab2rgb_u8(const float* L_centered, const float* ab, int32_t H, int32_t 
  * utils/util_distortion.py:18-23,85-100: skimage rgb2lab (float64) of an 8-bit H x W x 3 image, .float(), L - 50;
  * lab = [3][H][W].  Parity unpinned (skimage absent); round trip with dvc_lab2rgb_u8 tested. */
 int dvc_rgb8_to_lab(const uint8_t* rgb_hwc, int32_t H, int32_t W, float* lab, dvcStream stream);
+/* Frame ingest, geometric half: CenterPad(image_size)(image), utils/util_distortion.py:217-258 — skimage's
+ * anti-aliased resize (Gaussian pre-filter + bilinear sampling, mirror boundaries, float64) to the target width or
+ * height, centre crop, astype(uint8).  img = [H0][W0][3], out = [H][W][3].  Parity unpinned (skimage absent; the
+ * restatement is checked against the SciPy calls skimage makes). */
+size_t dvc_center_pad_workspace_bytes(int32_t H0, int32_t W0);
+int dvc_center_pad(const uint8_t* img, int32_t H0, int32_t W0, int32_t H, int32_t W, uint8_t* out, void* workspace,
+                   size_t workspace_bytes, dvcStream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense correlation (the north-star kernel).  Replaces models/NonlocalNet.py:469-500:
