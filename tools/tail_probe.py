@@ -58,3 +58,24 @@ for name, fn in (("clip (network resolution in, ab out)", lambda: cc.clip(small)
     fn()
     torch.cuda.synchronize()
     print(f"{name}: {K / (time.perf_counter() - t0):.1f} frames/s")
+
+# ---- ingest: 1080p 8-bit RGB -> CenterPad(432x768) -> centred Lab
+import numpy as np  # noqa: E402
+
+rgb = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (1080, 1920, 3), dtype=np.uint8)).to(dev)
+for _ in range(3):
+    tail.frame_ingest(rgb, (2 * H, 2 * W))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    tail.frame_ingest(rgb, (2 * H, 2 * W))
+e1.record()
+torch.cuda.synchronize()
+print(f"GPU ingest 1080x1920 RGB8 -> 432x768 Lab: {e0.elapsed_time(e1) / 20 * 1e3:.0f} us per frame")
+frames8 = [rgb.roll(7 * i, 1) for i in range(K)]
+cc.colorize_video(frames8[:4], frames8[0].flip(0).contiguous(), image_size=(2 * H, 2 * W))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+cc.colorize_video(frames8, frames8[0].flip(0).contiguous(), image_size=(2 * H, 2 * W))
+torch.cuda.synchronize()
+print(f"colorize_video (1080p RGB8 in -> 432x768 RGB8 out, exemplar prep included): {K / (time.perf_counter() - t0):.1f} frames/s")
