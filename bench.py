@@ -12,7 +12,9 @@ HIP streams, ColorVidNet recurrence on the main one; bit-identical to per-frame 
 are timed right after and reported as `config.per_frame_api_frames_per_s`; `--lookahead 0` times those instead).
 N=1 runs BASELINE.json configs[1].  With N>1 each rank colourises its own contiguous chunk of K frames (weak
 scaling; the exemplar-side tensors are computed on rank 0 and broadcast once over RCCL/xGMI; no collective in
-the per-frame path).  Rank 0 prints ONE JSON line on stdout; diagnostics go to stderr.
+the per-frame path).  `--gpus N` with N > 1 outside torch.distributed.run re-launches itself under it (one process
+per GPU); a world size different from --gpus, or fewer visible GPUs than requested, is an error — the line never
+reports an `n_gpus` other than the one asked for.  Rank 0 prints ONE JSON line on stdout; diagnostics go to stderr.
 """
 import argparse
 import contextlib
@@ -39,10 +41,25 @@ CORR_BYTES = 4.0 * (2 * P * C + 3 * P + 3 * P + P)      # 10.76 MB compulsory tr
 PATH_FLOPS = 348.4e9                                     # minimal whole-path FLOPs / frame
 PEAK_F32_MFMA_TFLOPS = 157.3                             # MI355X_MICROARCH.md, fp32 matrix
 PEAK_HBM_GBS = 8000.0
-# PMC-measured HBM traffic of one corr_fwd_kernel launch at P=5184 (profiles/r01_pmc_summary.md):
-# 102.2 MB read + 3.7 MB written vs 10.76 MB compulsory (phi is re-streamed through the per-XCD L2s)
-CORR_TRAFFIC_BYTES = 105.9e6
-CORR_TRAFFIC_SOURCE = "profiles/r01_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+# HBM traffic of one corr_fwd_kernel launch at P=5184.  rocprofv3 --pmc cannot run inside this process, so this
+# is an OFFLINE measurement (tools/pmc_corr.sh -> tools/summarize_profiles.py), not a number of this run: the
+# line names the summary file it was read from and that file's hash.  (2 x FETCH_SIZE + WRITE_SIZE, the gfx950
+# correction of MI355X_MICROARCH.md; phi is re-streamed through the eight per-XCD L2s, hence >> 10.76 MB.)
+CORR_TRAFFIC_FILE = "profiles/corr_traffic.json"
+
+
+def corr_traffic():
+    """(bytes per launch or None, provenance dict) read from the committed offline PMC summary."""
+    import hashlib
+    path = os.path.join(ROOT, CORR_TRAFFIC_FILE)
+    try:
+        raw = open(path, "rb").read()
+        rec = json.loads(raw)
+        return float(rec["bytes_per_launch"]), {"kind": "offline rocprofv3 --pmc passes, not re-measured by this run",
+                                                "file": CORR_TRAFFIC_FILE, "sha256_16": hashlib.sha256(raw).hexdigest()[:16],
+                                                "measured_on": rec.get("measured_on"), "P": rec.get("P")}
+    except (OSError, ValueError, KeyError):
+        return None, {"kind": "unavailable", "file": CORR_TRAFFIC_FILE}
 
 
 def log(*a):
@@ -62,39 +79,79 @@ def build_nets(device):
     return nets, sd
 
 
-def cpu_baseline(sd, n_timed=4):
-    """Oracle (torch-CPU restatement of the reference, bit-exact vs the reference modules — see
-    oracle/pin_reference.py) timed on this box's host cores on the same workload."""
+def _cpu_leg(sd, threads, n_warm, n_timed):
+    """Median s/frame of the oracle's frame_colorization recurrence on `threads` host threads."""
     from dvc_amd import synth
     from oracle import dvc_oracle as O
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    # ATen's CPU kernels stop scaling (and oversubscribe badly) far below a 256-thread host;
-    # use at most 32 threads and say so.
-    cores = max(1, min(avail, 32))
-    torch.set_num_threads(cores)
-    torch.set_flush_denormal(True)
-    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
+    torch.set_num_threads(threads)
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, 216, 384)
     with torch.no_grad():
-        fB = O.exemplar_features(IB, sd[0])
-        last = torch.zeros(1, 3, H, W)
+        fB = O.exemplar_features(IB, sd[0])                # once per clip, excluded like on the GPU side
+        last = torch.zeros(1, 3, 216, 384)
         times = []
-        for i in range(1 + n_timed):
-            fr = synth.synth_lab(synth.FRAME_SEED0 + i, H, W)
+        for i in range(n_warm + n_timed):
+            fr = synth.synth_lab(synth.FRAME_SEED0 + i, 216, 384)
             t0 = time.perf_counter()
             ab, _, _ = O.frame_colorization(fr, IB, last, fB, *sd, temperature=1e-10)
             dt = time.perf_counter() - t0
             last = torch.cat((fr[:, 0:1], ab), 1)
-            if i >= 1:
+            if i >= n_warm:
                 times.append(dt)
     times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_timed} timed + 1 warm-up 216x384 frames of the same synthetic clip, oracle "
-                      f"frame_colorization (reference op-for-op, exemplar side recomputed per frame as "
-                      f"the reference does), torch CPU fp32, {cores} threads of {avail} available, median {med * 1e3:.0f} ms/frame"}
+    return times[len(times) // 2]
+
+
+def cpu_baseline(sd):
+    """the reference's path on this box's host cores, same synthetic clip, fp32, flush-denormal,
+    k = every available thread and k = 1, >= 5 timed frames each, median.  What is timed is the oracle — the
+    op-for-op torch-CPU restatement that oracle/pin_reference.py shows bit-identical to the unmodified reference
+    modules (`kind: "port"`; /root/reference does not exist on the GPU box).  ATen's CPU kernels stop scaling well
+    below a 256-thread host, so a 32-thread leg is timed too and `value` is the FASTEST of the three."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_flush_denormal(True)
+    keep = torch.get_num_threads()
+    legs = {}
+    try:
+        for k, warm, timed in sorted({(avail, 2, 5), (min(avail, 32), 2, 5), (1, 1, 5)}):
+            med = _cpu_leg(sd, k, warm, timed)
+            legs[k] = {"frames_per_s": round(1.0 / med, 4), "median_ms_per_frame": round(med * 1e3, 1),
+                       "warmup_frames": warm, "timed_frames": timed}
+            log(f"[bench] cpu baseline, {k} thread(s): {med * 1e3:.0f} ms/frame")
+    finally:
+        torch.set_num_threads(keep)
+    best = max(legs, key=lambda k: legs[k]["frames_per_s"])
+    cpu_model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": legs[best]["frames_per_s"], "unit": "frames/s", "cores": best, "kind": "port",
+            "sample": "216x384 frames of the same synthetic clip (exemplar seed 2, frames 1000..), oracle "
+                      "frame_colorization recurrence = the reference op for op (exemplar side recomputed per frame as "
+                      "the reference does), torch CPU fp32, flush-denormal; median over the timed frames of each leg; "
+                      f"`value` is the fastest leg ({best} threads)",
+            "host": {"threads_available": avail, "cpu": cpu_model},
+            "by_threads": {str(k): v for k, v in sorted(legs.items())}}
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start N ranks ourselves."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] launching", " ".join(cmd))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -119,12 +176,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # launched by torch.distributed.run
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.gpus < 1:
+        sys.exit("[bench] --gpus must be >= 1")
+    if torch.cuda.device_count() < args.gpus:
+        sys.exit(f"[bench] --gpus {args.gpus} requested but only {torch.cuda.device_count()} GPU(s) visible: refusing to "
+                 "print a line for a different n_gpus")
+    if not use_dist and args.gpus > 1:
+        sys.exit(relaunch_under_torchrun(args.gpus))
+    if use_dist and world != args.gpus:
+        sys.exit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line for a different n_gpus")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    global H, W, P, CORR_FLOPS, CORR_BYTES, PATH_FLOPS, CORR_TRAFFIC_BYTES
+    global H, W, P, CORR_FLOPS, CORR_BYTES, PATH_FLOPS
     if args.hw != "216x384":
         H, W = (int(v) for v in args.hw.lower().split("x"))
         assert H % 16 == 0 and W % 16 == 0, "--hw: multiples of 16"
@@ -133,7 +199,6 @@ def main():
         CORR_FLOPS = 2.0 * P * P * C + 2.0 * P * P * 3
         CORR_BYTES = 4.0 * (2 * P * C + 3 * P + 3 * P + P)
         PATH_FLOPS = (348.4e9 - 13.92e9) * scale + CORR_FLOPS     # convolutions scale with the pixels
-        CORR_TRAFFIC_BYTES = None
         args.no_cpu_baseline = True
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -152,8 +217,6 @@ def main():
             os.dup2(saved, 1)
             os.close(saved)
     n_gpus = world
-    if args.gpus != world:
-        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}")
 
     from dvc_amd import ops, synth
     from dvc_amd.frame import ClipColorizer
@@ -222,13 +285,22 @@ def main():
     assert torch.isfinite(last).all(), "non-finite output"
     fps = n_gpus * K / elapsed
 
-    # ---- roofline of the north-star kernel: HIP events on the launch stream, same inputs
+    # ---- roofline of the north-star kernel: HIP events on the launch stream, on the CLIP'S OWN operands — theta of
+    # the first timed frame (VGG19 -> WarpNet heads/trunk -> 1x1 -> centre/normalise, exactly what frame_colorization
+    # feeds the kernel), phi and the pooled Lab of the exemplar
     roof = None
     if rank == 0:
-        g = torch.Generator().manual_seed(1)
-        th = ops.corr_prepare(torch.randn(1, C, P, generator=g).to(device))
-        ph = ops.corr_prepare(torch.randn(1, C, P, generator=g).to(device))
-        bl = torch.randn(1, 3, P, generator=g).to(device)
+        from dvc_amd.frame import VGG_OUT
+        from dvc_amd.util import feature_normalize, gray2rgb_batch
+        vgg, warp, _ = nets
+        fr = frames[Wm]
+        fA = vgg(gray2rgb_batch(fr[:, 0:1]), VGG_OUT)
+        th = warp.project("theta", warp.features(*[feature_normalize(t) for t in fA[1:]]))
+        if cc.ex_cache is not None and not isinstance(cc.ex_cache[0], tuple):
+            ph, bl4 = cc.ex_cache
+        else:   # (--no-exemplar-cache / bf16 cache layout: rebuild the fp32 exemplar side for this leg)
+            ph, bl4 = warp.exemplar_side(cc.IB_lab, *[feature_normalize(t) for t in cc.features_B[1:]], bf16=False)
+        bl = bl4.view(1, 3, -1)
         for _ in range(3):
             ops.corr_fwd(th, ph, bl, 1e-10, H // 4, W // 4)
         reps = 30
@@ -240,12 +312,12 @@ def main():
         torch.cuda.synchronize()
         t_corr = e0.elapsed_time(e1) * 1e-3 / reps      # fused kernel + its (tiny) merge kernel
         achieved = CORR_FLOPS / t_corr / 1e12
+        traffic, traffic_src = corr_traffic() if (H, W) == (216, 384) else (None, {"kind": "not measured at this size"})
         roof = {"kernel": "corr_fwd_kernel (+corr_merge_kernel)", "bound": "mfma",
                 "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                # HBM bytes per launch from the separate rocprofv3 --pmc passes (2 x FETCH_SIZE + WRITE_SIZE,
-                # gfx950 correction per MI355X_MICROARCH.md); measured offline, see profiles/*_pmc_summary.md
-                "traffic": CORR_TRAFFIC_BYTES, "traffic_source": CORR_TRAFFIC_SOURCE,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "operands": "theta of the first timed frame, phi / pooled Lab of the exemplar (the clip's own features)",
                 "avg_launch_us": round(t_corr * 1e6, 2),
                 "hbm_view": {"achieved": round(CORR_BYTES / t_corr / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": round(CORR_BYTES / t_corr / 1e9 / PEAK_HBM_GBS, 5),

@@ -71,6 +71,13 @@ class ClipColorizer:
         self._main_stream = None
         self._tail_stream = None
 
+    def prepare(self):
+        """Pack all weights of the three networks on the current stream (idempotent, cheap when warm)."""
+        for net in (self.vgg, self.warp, self.col):
+            prep = getattr(net, "prepare", None)
+            if prep is not None:
+                prep()
+
     def set_exemplar(self, IB_lab):
         """test.py:61-66: Lab -> RGB -> VGG features of the reference image."""
         IB_lab = IB_lab.detach().contiguous().float()
@@ -83,13 +90,33 @@ class ClipColorizer:
             self.ex_cache = self.warp.exemplar_side(IB_lab, *nB, bf16=self.warp._use_bf16(self.temperature, 1))
         return self.features_B
 
-    def exemplar_cache_shapes(self, lab_shape):
-        """Shapes of (phi, pooled Lab) for an exemplar of `lab_shape` (used by parallel.broadcast_exemplar)."""
+    def exemplar_cache_spec(self, lab_shape):
+        """[(shape, dtype)] of the flat tensor list `exemplar_cache_tensors()` yields for an exemplar of
+        `lab_shape` — what a rank that did not compute the exemplar side must allocate to receive it
+        (parallel.broadcast_exemplar).  fp32 correlation: phi [n,256,P], pooled Lab [n,3,h,w]; bf16 candidate
+        filter: phi as ([n,P,256] fp32, [n,P,256] bf16 bit patterns in int16), pooled Lab."""
         n, _, H, W = lab_shape
         h, w = int(H / 4), int(W / 4)
         if self.warp._use_bf16(self.temperature, 1):
-            raise NotImplementedError("broadcasting a bf16 exemplar cache: let every rank call set_exemplar")
-        return [(n, 256, h * w), (n, 3, h, w)]
+            return [((n, h * w, 256), torch.float32), ((n, h * w, 256), torch.int16), ((n, 3, h, w), torch.float32)]
+        return [((n, 256, h * w), torch.float32), ((n, 3, h, w), torch.float32)]
+
+    def exemplar_cache_shapes(self, lab_shape):
+        """Shapes only (kept for callers of the fp32 layout)."""
+        return [s for s, _ in self.exemplar_cache_spec(lab_shape)]
+
+    def exemplar_cache_tensors(self):
+        """The exemplar cache as a flat list of contiguous tensors, in `exemplar_cache_spec` order."""
+        phi, blab = self.ex_cache
+        flat = list(phi) if isinstance(phi, tuple) else [phi]
+        return [t.contiguous() for t in flat + [blab]]
+
+    def load_exemplar_cache(self, IB_lab, tensors):
+        """Install an exemplar cache received from another rank (inverse of exemplar_cache_tensors)."""
+        tensors = list(tensors)
+        self.IB_lab = IB_lab
+        self.features_B = None          # not needed once the exemplar side is cached
+        self.ex_cache = ((tensors[0], tensors[1]), tensors[2]) if len(tensors) == 3 else (tensors[0], tensors[1])
 
     def frame(self, IA_lab, IA_last_lab):
         ab, nl, _ = frame_colorization(IA_lab, self.IB_lab, IA_last_lab, self.features_B, self.vgg, self.warp,
@@ -125,6 +152,9 @@ class ClipColorizer:
             self.last_lab = last
             return outs
         caller = torch.cuda.current_stream()
+        # every lazily packed weight is produced here, on the caller's stream, before the fork: a side
+        # stream must never be the one that packs a weight another side stream reads (nets._PackCache)
+        self.prepare()
         lo_prio, hi_prio = torch.cuda.Stream.priority_range()
         if self._main_stream is None:
             # the ColorVidNet recurrence is the critical path: highest priority; the front ends fill in
@@ -220,9 +250,12 @@ class ClipColorizer:
         """colorize_video of test.py:29-121 without its file I/O: 8-bit RGB device frames (any size) in, 8-bit RGB
         colourised frames (image_size) out.  `image_size` is the size CenterPad produces (twice the network
         resolution; the reference's --image_size is the network resolution and test.py:163 doubles it).
-        reference_rgb8=None with frame_propagate=True uses the first frame as the exemplar (test.py:50)."""
+        With frame_propagate=True the first frame is the exemplar and `reference_rgb8` is ignored, exactly as
+        test.py:50 ignores `reference_file` in that mode."""
         from . import tail
         large = [tail.frame_ingest(f, image_size) for f in frames_rgb8]
-        ref_large = large[0] if (frame_propagate and reference_rgb8 is None) else tail.frame_ingest(reference_rgb8, image_size)
+        if not frame_propagate and reference_rgb8 is None:
+            raise ValueError("colorize_video: reference_rgb8 is required unless frame_propagate=True")
+        ref_large = large[0] if frame_propagate else tail.frame_ingest(reference_rgb8, image_size)
         self.set_exemplar(tail.downsample_half(ref_large))                      # test.py:57-66
         return self.clip_rgb(large, wls_filter_on, lambda_value, sigma_color, frame_propagate=frame_propagate)

@@ -31,8 +31,17 @@ class _PackCache:
         tag = (param.data_ptr(), param._version, str(param.device))
         hit = self._d.get(key)
         if hit is None or hit[0] != tag:
+            # Cold path (first use, or after load_state_dict / .cuda()).  The packed tensor is produced
+            # on whatever stream is current and then read by kernels on ANY stream (the clip driver runs
+            # front ends on side streams), so the miss is made a device-wide ordering point: everything
+            # that may still read the entry being replaced has finished before it is dropped, and the new
+            # entry is complete before any stream can see it.  `prepare()` takes all misses up front.
+            if param.is_cuda:
+                torch.cuda.synchronize(param.device)
             with torch.no_grad():
                 hit = (tag, fn(param))
+            if param.is_cuda:
+                torch.cuda.synchronize(param.device)
             self._d[key] = hit
         return hit[1]
 
@@ -41,6 +50,13 @@ def _check_input(x, name):
     if not x.is_cuda:
         raise RuntimeError(f"{name}: input is on {x.device}; the MI355X HIP path has no CPU fallback "
                            "(move the module and its inputs to the GPU with .cuda())")
+    if x.requires_grad and torch.is_grad_enabled():
+        # the reference would record an autograd graph here (train.py:402-427); this forward is
+        # inference-only, so say so instead of silently returning a tensor without history
+        raise NotImplementedError(
+            f"{name}: an input requires grad and autograd is enabled, but the HIP forward is inference-only "
+            "(no backward kernels). Call it under torch.no_grad() as test.py:83 does, or detach the input; "
+            "gradients exist only for the fused correlation, see dvc_amd.corr_autograd.")
 
 
 # ================================================================================================ VGG19
@@ -61,6 +77,22 @@ class VGG19_pytorch(nn.Module):
         if swap_bgr:  # fold RGB->BGR of vgg_preprocess into conv1_1's input-channel order
             return self._cache.get(name + ":bgr", conv.weight, lambda w: ops.pack_conv_weight(w.flip(1)))
         return self._cache.get(name, conv.weight, ops.pack_conv_weight)
+
+    def _pre_affine(self):
+        """vgg_preprocess (utils/util.py:347-352) as a per-channel affine on the stored R,G,B channels:
+        BGR channel c' = 2-c gets (x - mean[c'])*255 = x*255 - 255*mean[c']."""
+        w = self.conv1_1.weight
+        sc = self._cache.get("pre:scale", w, lambda w: torch.full((3,), 255.0, device=w.device))
+        sh = self._cache.get("pre:shift", w, lambda w: torch.tensor(
+            [-255.0 * _VGG_MEAN_BGR[2], -255.0 * _VGG_MEAN_BGR[1], -255.0 * _VGG_MEAN_BGR[0]], device=w.device))
+        return sc, sh
+
+    def prepare(self):
+        """Pack every weight now, on the current stream (see _PackCache.get)."""
+        for name, _, _ in arch.VGG_CONVS:
+            self._packed(name)
+        self._packed("conv1_1", swap_bgr=True)
+        self._pre_affine()
 
     def forward(self, x, out_keys, preprocess=True):
         _check_input(x, "VGG19_pytorch")
@@ -83,13 +115,8 @@ class VGG19_pytorch(nn.Module):
                 conv = getattr(self, name)
                 bias = conv.bias.detach()
                 if name == "conv1_1" and preprocess:
-                    # vgg_preprocess (utils/util.py:347-352) folded into the load: stored channel c is
-                    # R,G,B; BGR channel c' = 2-c gets (x - mean[c'])*255 = x*255 - 255*mean[c'].
-                    sc = self._cache.get("pre:scale", conv.weight,
-                                         lambda w: torch.full((3,), 255.0, device=w.device))
-                    sh = self._cache.get("pre:shift", conv.weight, lambda w: torch.tensor(
-                        [-255.0 * _VGG_MEAN_BGR[2], -255.0 * _VGG_MEAN_BGR[1], -255.0 * _VGG_MEAN_BGR[0]],
-                        device=w.device))
+                    # vgg_preprocess folded into the load (BGR weight flip + per-channel affine)
+                    sc, sh = self._pre_affine()
                     cur = ops.conv2d(cur, self._packed(name, swap_bgr=True), bias, act=ops.ACT_RELU,
                                      in_scale=sc.repeat(N), in_shift=sh.repeat(N))
                 else:
@@ -145,6 +172,18 @@ class WarpNet(nn.Module):
 
     def _pk(self, key, conv):
         return self._cache.get(key, conv.weight, ops.pack_conv_weight)
+
+    def prepare(self):
+        """Pack every weight now, on the current stream (see _PackCache.get)."""
+        for name in arch.WARP_HEAD_ORDER:
+            seq = getattr(self, name)
+            for (ci, _, _, _, _) in arch.WARP_HEADS[name]["convs"]:
+                self._pk(f"{name}.{ci}", seq[ci])
+        for b in range(arch.WARP_NUM_RESBLOCKS):
+            self._pk(f"layer.{b}.conv1", self.layer[b].conv1)
+            self._pk(f"layer.{b}.conv2", self.layer[b].conv2)
+        self._pk("theta", self.theta)
+        self._pk("phi", self.phi)
 
     def features(self, r2, r3, r4, r5):
         """Heads + concat + residual trunk for one side (NonlocalNet.py:451-465) -> [N,256,h,w]."""
@@ -306,12 +345,28 @@ class ColorVidNet(nn.Module):
             m = m[int(part)] if part.isdigit() else getattr(m, part)
         return m
 
+    def _ss_weight(self, key):
+        return self._cache.get(key, self._mod(key).weight, lambda w: w.detach().reshape(-1).contiguous())
+
+    def _out_weight(self):
+        out = self._mod(arch.CVN_OUT["key"])
+        return self._cache.get("conv10_ab", out.weight, lambda w: w.detach().reshape(w.shape[0], -1).contiguous())
+
+    def prepare(self):
+        """Pack every weight now, on the current stream (see _PackCache.get)."""
+        for c in arch.CVN_CONVS:
+            self._cache.get(c["key"], self._mod(c["key"]).weight, ops.pack_conv_weight)
+            if c["pre"] == "norm_ss":
+                self._ss_weight(c["ss"])
+        self._out_weight()
+
     def forward(self, x):
         """ x: gray image (1 channel), ab(2 channel), ab_err, ba_err"""
         _check_input(x, "ColorVidNet")
         x = x.detach().contiguous().float()
         acts = {"x": x}
         normed = {}
+        ss_weight = self._ss_weight
 
         # activations that are normalised for two consumers (skip convolution: plain; next block: * `_ss`
         # weight, stride 2) get both tensors from one launch
@@ -322,8 +377,6 @@ class ColorVidNet(nn.Module):
             """InstanceNorm2d(src) [* the depthwise `_ss` weight, stride 2] as a tensor (ColorVidNet.py:85-94,12)."""
             k = (src, ss_key)
             if k not in normed:
-                def ss_weight(key):
-                    return self._cache.get(key, self._mod(key).weight, lambda w: w.detach().reshape(-1).contiguous())
                 if src in both:
                     normed[(src, None)], normed[(src, both[src])] = ops.instnorm_apply(
                         acts[src], eps=1e-5, second=(ss_weight(both[src]), 2))
@@ -351,5 +404,4 @@ class ColorVidNet(nn.Module):
                 kw["residual"] = acts[c["add"]]
             acts[c["dst"]] = ops.conv2d(src, wp, conv.bias.detach(), **kw)
         out = self._mod(arch.CVN_OUT["key"])
-        w2 = self._cache.get("conv10_ab", out.weight, lambda w: w.detach().reshape(w.shape[0], -1).contiguous())
-        return ops.conv1x1_small(acts["c10_2"], w2, out.bias.detach(), act=ops.ACT_TANH128)
+        return ops.conv1x1_small(acts["c10_2"], self._out_weight(), out.bias.detach(), act=ops.ACT_TANH128)

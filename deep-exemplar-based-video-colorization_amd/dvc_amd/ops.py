@@ -34,6 +34,11 @@ def _need(t, name):
         raise RuntimeError(f"dvc_amd: `{name}` must be float32 (got {t.dtype})")
     if not t.is_contiguous():
         raise RuntimeError(f"dvc_amd: `{name}` must be contiguous")
+    if t.device.index != torch.cuda.current_device():
+        # libdvc_hip launches on the CURRENT device's current stream and never calls hipSetDevice:
+        # one process per GPU (torch.cuda.set_device(LOCAL_RANK)) is the supported mode
+        raise RuntimeError(f"dvc_amd: `{name}` lives on {t.device} but the current device is cuda:"
+                           f"{torch.cuda.current_device()}; call torch.cuda.set_device / use torch.cuda.device(...)")
 
 
 conv_record = None   # set to a list to log every conv2d launch (tools/tune_conv.py)

@@ -34,28 +34,28 @@ def chunk_bounds(n_frames, world, rank):
 def broadcast_exemplar(cc, IB_lab, shape, device, src=0):
     """Give every rank's ClipColorizer the same exemplar state, computing the exemplar side once.
 
-    `cc` needs: .cache_exemplar, .set_exemplar(IB_lab), .IB_lab, .features_B, .ex_cache,
-    and .exemplar_cache_shapes(shape) when cache_exemplar is on."""
+    `cc` needs: .cache_exemplar, .set_exemplar(IB_lab), .IB_lab, and — when cache_exemplar is on —
+    .exemplar_cache_spec(shape) / .exemplar_cache_tensors() / .load_exemplar_cache(IB, tensors)
+    (fp32 cache: phi + pooled Lab, 5.4 MB at 216x384; bf16 candidate-filter cache: phi in fp32 and bf16 +
+    pooled Lab, 8 MB).  One broadcast per tensor, rank `src` -> all, once per clip."""
     world, rank = _world()
     if not (dist.is_available() and dist.is_initialized()):
         cc.set_exemplar(IB_lab)
         return
     IB = IB_lab.contiguous() if rank == src else torch.empty(shape, device=device, dtype=torch.float32)
     dist.broadcast(IB, src)
-    if not cc.cache_exemplar or getattr(getattr(cc, "warp", None), "corr_precision", "fp32") != "fp32":
-        cc.set_exemplar(IB)          # every rank prepares the exemplar side itself
+    if not cc.cache_exemplar:
+        cc.set_exemplar(IB)          # every rank prepares (and re-prepares per frame) the exemplar side itself
         return
     if rank == src:
         cc.set_exemplar(IB)
-        bufs = [t.contiguous() for t in cc.ex_cache]
+        bufs = cc.exemplar_cache_tensors()
     else:
-        bufs = [torch.empty(s, device=device, dtype=torch.float32) for s in cc.exemplar_cache_shapes(shape)]
+        bufs = [torch.empty(s, device=device, dtype=dt) for s, dt in cc.exemplar_cache_spec(shape)]
     for b in bufs:
         dist.broadcast(b, src)
     if rank != src:
-        cc.IB_lab = IB
-        cc.features_B = None         # not needed once the exemplar side is cached
-        cc.ex_cache = tuple(bufs)
+        cc.load_exemplar_cache(IB, bufs)
 
 
 def colorize_clip_sharded(cc, frames_lab, IB_lab, device, gather=True, src=0):

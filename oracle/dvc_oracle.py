@@ -203,6 +203,34 @@ def correlate(theta, phi, B_lab_map, temperature, WTA_scale_weight=1):
     return y, sim, f
 
 
+def correlate_chunked(theta, phi, B_lab_map, temperature, rows=2048):
+    """`correlate` evaluated `rows` query rows at a time, so that the N x N matrix (1.72 GB fp32 at
+    432x768, several copies of it inside `correlate`) never has to exist at once.  Same operations per
+    row (matmul row block, max, / T, softmax, matmul with the pooled colours); a BLAS row block may round
+    differently from the full product in the last place, so this is the oracle for sizes where
+    `correlate` does not fit, and is itself checked against `correlate` at small sizes
+    (tests/test_oracle_golden.py).  WTA_scale_weight == 1 only.
+    Returns (y n x 3 x h x w, sim n x 1 x h x w, argmax n x N, top-1/top-2 gap n x N)."""
+    n, channel, H, W = B_lab_map.shape
+    fh, fw = int(H / 4), int(W / 4)
+    N = theta.shape[2]
+    B_lab = F.avg_pool2d(B_lab_map, 4).view(n, channel, -1).permute(0, 2, 1)
+    tp = theta.permute(0, 2, 1)
+    y = torch.empty(n, N, channel, dtype=theta.dtype)
+    sim = torch.empty(n, N, dtype=theta.dtype)
+    amax = torch.empty(n, N, dtype=torch.long)
+    gap = torch.empty(n, N, dtype=theta.dtype)
+    for r0 in range(0, N, rows):
+        f = torch.matmul(tp[:, r0:r0 + rows], phi)
+        top2 = torch.topk(f, 2, dim=-1)
+        sim[:, r0:r0 + rows] = top2[0][..., 0]
+        amax[:, r0:r0 + rows] = f.argmax(-1)
+        gap[:, r0:r0 + rows] = top2[0][..., 0] - top2[0][..., 1]
+        y[:, r0:r0 + rows] = torch.matmul(F.softmax(f / temperature, dim=-1), B_lab)
+    y = y.permute(0, 2, 1).contiguous().view(n, channel, fh, fw)
+    return y, sim.view(n, 1, fh, fw), amax, gap
+
+
 def warpnet_forward(sd, B_lab_map, A2, A3, A4, A5, B2, B3, B4, B5, temperature=0.001 * 5,
                     detach_flag=False, WTA_scale_weight=1, feature_noise=0, taps=None):
     """WarpNet.forward, models/NonlocalNet.py:427-502.  `taps` (dict) receives intermediates."""

@@ -37,8 +37,14 @@ class OracleColorizer:
                 blab = torch.nn.functional.avg_pool2d(IB_lab, 4)
                 self.ex_cache = (phi, blab)
 
-    def exemplar_cache_shapes(self, s):
-        return [(s[0], 256, (s[2] // 4) * (s[3] // 4)), (s[0], 3, s[2] // 4, s[3] // 4)]
+    def exemplar_cache_spec(self, s):
+        return [((s[0], 256, (s[2] // 4) * (s[3] // 4)), torch.float32), ((s[0], 3, s[2] // 4, s[3] // 4), torch.float32)]
+
+    def exemplar_cache_tensors(self):
+        return [t.contiguous() for t in self.ex_cache]
+
+    def load_exemplar_cache(self, IB_lab, tensors):
+        self.IB_lab, self.features_B, self.ex_cache = IB_lab, None, tuple(tensors)
 
     def clip(self, frames):
         from oracle import dvc_oracle as O
@@ -110,3 +116,33 @@ def test_chunk_bounds_cover_and_balance():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_clipcolorizer_exemplar_cache_spec_and_roundtrip():
+    """The real ClipColorizer's side of the broadcast protocol (shapes/dtypes a receiving rank allocates, flat
+    tensor order, re-installation) for both cache layouts: fp32 (phi, pooled Lab) and the bf16 candidate filter
+    ((phi fp32, phi bf16-as-int16), pooled Lab).  Host logic only: no kernel runs."""
+    import contextlib
+    import io
+    from dvc_amd.frame import ClipColorizer
+    from models.NonlocalNet import WarpNet
+    with contextlib.redirect_stdout(io.StringIO()):
+        warp = WarpNet(1)
+    cc = ClipColorizer(None, warp, None, temperature=1e-10)
+    shape = (1, 3, 216, 384)
+    P = 54 * 96
+    assert cc.exemplar_cache_spec(shape) == [((1, 256, P), torch.float32), ((1, 3, 54, 96), torch.float32)]
+    assert cc.exemplar_cache_shapes(shape) == [(1, 256, P), (1, 3, 54, 96)]
+    bufs = [torch.zeros(s, dtype=dt) for s, dt in cc.exemplar_cache_spec(shape)]
+    cc.load_exemplar_cache(torch.zeros(shape), bufs)
+    assert cc.ex_cache[0] is bufs[0] and cc.ex_cache[1] is bufs[1] and cc.features_B is None
+    assert all(a is b or torch.equal(a, b) for a, b in zip(cc.exemplar_cache_tensors(), bufs))
+    warp.corr_precision = "bf16"
+    spec = cc.exemplar_cache_spec(shape)
+    assert spec == [((1, P, 256), torch.float32), ((1, P, 256), torch.int16), ((1, 3, 54, 96), torch.float32)]
+    bufs = [torch.zeros(s, dtype=dt) for s, dt in spec]
+    cc.load_exemplar_cache(torch.zeros(shape), bufs)
+    assert isinstance(cc.ex_cache[0], tuple) and cc.ex_cache[0][1].dtype == torch.int16
+    assert [t.dtype for t in cc.exemplar_cache_tensors()] == [dt for _, dt in spec]
+    cc.temperature = 0.01            # soft temperature: the bf16 filter is not used, fp32 layout again
+    assert len(cc.exemplar_cache_spec(shape)) == 2
