@@ -79,50 +79,98 @@ def build_nets(device):
     return nets, sd
 
 
-def _cpu_leg(sd, threads, n_warm, n_timed):
-    """Median s/frame of the oracle's frame_colorization recurrence on `threads` host threads."""
+def host_cpus():
+    """(usable hardware threads, how that was determined): the affinity mask, capped by the cgroup CPU quota — a
+    container may see 256 threads in its mask while being allowed 32 CPUs' worth of time, and an ATen thread pool
+    sized for the mask then runs ~100x slower than one sized for the quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    how = "sched_getaffinity"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period))
+                if q < n:
+                    n, how = q, f"cgroup quota ({path})"
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, how
+
+
+def _cpu_leg(sd, threads, n_warm, n_timed, budget_s):
+    """Median s/frame of the oracle's frame_colorization recurrence on `threads` host threads; gives up (returning
+    what it has) once `budget_s` seconds are spent — the leg must never eat the GPU box's time."""
     from dvc_amd import synth
     from oracle import dvc_oracle as O
     torch.set_num_threads(threads)
     IB = synth.synth_lab(synth.EXEMPLAR_SEED, 216, 384)
+    t_start = time.perf_counter()
     with torch.no_grad():
         fB = O.exemplar_features(IB, sd[0])                # once per clip, excluded like on the GPU side
         last = torch.zeros(1, 3, 216, 384)
-        times = []
+        times, warm = [], []
         for i in range(n_warm + n_timed):
             fr = synth.synth_lab(synth.FRAME_SEED0 + i, 216, 384)
             t0 = time.perf_counter()
             ab, _, _ = O.frame_colorization(fr, IB, last, fB, *sd, temperature=1e-10)
             dt = time.perf_counter() - t0
             last = torch.cat((fr[:, 0:1], ab), 1)
-            if i >= n_warm:
-                times.append(dt)
-    times.sort()
-    return times[len(times) // 2]
+            (times if i >= n_warm else warm).append(dt)
+            if time.perf_counter() - t_start > budget_s:
+                break
+    done = sorted(times) if times else sorted(warm)
+    return done[len(done) // 2], len(times)
 
 
 def cpu_baseline(sd):
     """the reference's path on this box's host cores, same synthetic clip, fp32, flush-denormal,
-    k = every available thread and k = 1, >= 5 timed frames each, median.  What is timed is the oracle — the
+    k = every usable hardware thread and k = 1, 5 timed frames each, median.  What is timed is the oracle — the
     op-for-op torch-CPU restatement that oracle/pin_reference.py shows bit-identical to the unmodified reference
     modules (`kind: "port"`; /root/reference does not exist on the GPU box).  ATen's CPU kernels stop scaling well
-    below a 256-thread host, so a 32-thread leg is timed too and `value` is the FASTEST of the three."""
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
+    below a 128-thread host, so a 32-thread leg is timed too and `value` is the FASTEST leg.  Every leg has a time
+    budget (the r02 box advertised 256 threads under a smaller CPU quota: 77 s per frame with a 256-thread pool)."""
+    avail, how = host_cpus()
     torch.set_flush_denormal(True)
     keep = torch.get_num_threads()
     legs = {}
+
+    def probe(k):   # one 6-GFLOP convolution, best of 3: a cheap look at how a k-thread pool behaves on this host
+        torch.set_num_threads(k)
+        x, w = torch.randn(1, 64, 216, 384), torch.randn(64, 64, 3, 3)
+        best = float("inf")
+        with torch.no_grad():
+            for _ in range(3):
+                t0 = time.perf_counter()
+                torch.nn.functional.conv2d(x, w, padding=1)
+                best = min(best, time.perf_counter() - t0)
+        return best
+
     try:
-        for k, warm, timed in sorted({(avail, 2, 5), (min(avail, 32), 2, 5), (1, 1, 5)}):
-            med = _cpu_leg(sd, k, warm, timed)
+        for k, warm, timed, budget in sorted({(avail, 1, 5, 20.0), (min(avail, 32), 1, 5, 20.0), (1, 1, 5, 25.0)}):
+            if k > 32:
+                p_all, p_32 = probe(k), probe(32)
+                if p_all > 3.0 * p_32:
+                    legs[k] = {"frames_per_s": None, "note": f"skipped: a {k}-thread ATen pool is oversubscribed on this host "
+                                                             f"(6-GFLOP conv probe {p_all * 1e3:.0f} ms vs {p_32 * 1e3:.0f} ms on 32 threads)"}
+                    log(f"[bench] cpu baseline, {k} threads: skipped ({legs[k]['note']})")
+                    continue
+            med, n_done = _cpu_leg(sd, k, warm, timed, budget)
             legs[k] = {"frames_per_s": round(1.0 / med, 4), "median_ms_per_frame": round(med * 1e3, 1),
-                       "warmup_frames": warm, "timed_frames": timed}
-            log(f"[bench] cpu baseline, {k} thread(s): {med * 1e3:.0f} ms/frame")
+                       "warmup_frames": warm, "timed_frames": n_done}
+            if n_done < timed:
+                legs[k]["note"] = f"stopped after {budget:.0f} s"
+            log(f"[bench] cpu baseline, {k} thread(s): {med * 1e3:.0f} ms/frame ({n_done} timed)")
     finally:
         torch.set_num_threads(keep)
-    best = max(legs, key=lambda k: legs[k]["frames_per_s"])
+    best = max((k for k in legs if legs[k]["frames_per_s"]), key=lambda k: legs[k]["frames_per_s"])
     cpu_model = ""
     try:
         for ln in open("/proc/cpuinfo"):
@@ -134,9 +182,9 @@ def cpu_baseline(sd):
     return {"value": legs[best]["frames_per_s"], "unit": "frames/s", "cores": best, "kind": "port",
             "sample": "216x384 frames of the same synthetic clip (exemplar seed 2, frames 1000..), oracle "
                       "frame_colorization recurrence = the reference op for op (exemplar side recomputed per frame as "
-                      "the reference does), torch CPU fp32, flush-denormal; median over the timed frames of each leg; "
+                      "the reference does), torch CPU fp32, flush-denormal; 1 warm-up + 5 timed frames per leg, median; "
                       f"`value` is the fastest leg ({best} threads)",
-            "host": {"threads_available": avail, "cpu": cpu_model},
+            "host": {"threads_usable": avail, "threads_usable_from": how, "cpu": cpu_model},
             "by_threads": {str(k): v for k, v in sorted(legs.items())}}
 
 

@@ -2,6 +2,7 @@
 // The kernel template lives in conv_kernel.h; its instantiations are split over conv_k3d1.hip,
 // conv_k3d2.hip, conv_k1.hip and conv_gen.hip.
 #include "conv_kernel.h"
+#include "conv_sk_kernel.h"
 
 static int virt_dim(int S, int up, int sub) {
     if (up == 2) return S * 2;
@@ -66,6 +67,20 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
         if (res) o += res[(long)n * res_bs + i + k];
         y[(long)n * y_bs + i + k] = apply_act(o, act, slope);
     }
+}
+
+// compute units of the current device (256 on MI355X), queried once
+static int conv_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            n = p.multiProcessorCount;
+        else
+            n = 256;
+    }
+    return n;
 }
 
 static int g_conv_dbg = 0;
@@ -136,6 +151,45 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     if (gen) DVC_REQUIRE(d->ksize == 3, "dvc_conv2d: stride-2 / dilated variant supports ksize 3 only");
     int cfg = d->cfg;
     bool allow_dma = true;
+    if (cfg >= 32) {
+        // 32 + tile configuration: stream-K decomposition (conv_sk_kernel.h); split_k = workgroups per CU (0 -> 2)
+        cfg -= 32;
+        DVC_REQUIRE(cfg < 7, "dvc_conv2d: cfg out of range");
+        // 5 / 6: tile configurations 4 / 3 with two independent accumulator chains per tile
+        const ConvCfg& c = kConvCfgs[cfg == 5 ? 4 : cfg == 6 ? 3 : cfg];
+        const int mt = 32 * c.wm * c.rm, ph = c.wn * c.rn * rpt, ck = conv_ck(d->ksize, c.rm * c.rn, false);
+        DVC_REQUIRE(!gen && !in_scale && !d->in_prelu && d->Cin % ck == 0 && d->Cout % mt == 0,
+                    "dvc_conv2d: the stream-K path needs a plain stride-1 layer (no fused input transform, Cin %% %d == 0, "
+                    "Cout %% %d == 0)", ck, mt);
+        DVC_REQUIRE(workspace, "dvc_conv2d: the stream-K path needs a workspace");
+        ConvSkArgs sk;
+        sk.k = a;
+        sk.k.split = 1; sk.k.chunks_per_split = 0; sk.k.part = nullptr;
+        sk.tiles_x = cdiv(OW, tw);
+        sk.px_tiles = sk.tiles_x * cdiv(OH, ph);
+        sk.co_blocks = d->Cout / mt;
+        sk.NC = d->Cin / ck;
+        const long tiles = (long)d->N * sk.co_blocks * sk.px_tiles;
+        sk.U = tiles * sk.NC;
+        DVC_REQUIRE(tiles < (1L << 30), "dvc_conv2d: too many tiles");
+        int per_cu = d->split_k > 0 ? d->split_k : 2;
+        if (per_cu > 2) per_cu = 2;     // the kernel is register-allocated for 2 workgroups per CU
+        long G = (long)per_cu * conv_num_cus();
+        if (G > sk.U) G = sk.U;
+        const size_t slot = (size_t)mt * (c.wn * c.rn * 32) * sizeof(float);
+        DVC_REQUIRE((size_t)G * 2 * slot <= workspace_bytes, "dvc_conv2d: workspace too small for the stream-K slots");
+        sk.part = reinterpret_cast<float*>(workspace);
+        ConvSkLaunch L;
+        L.grid = dim3((unsigned)G);
+        L.fix_grid = dim3((unsigned)tiles);
+        L.need_fixup = !(sk.U % G == 0 && (sk.U / G) % sk.NC == 0);
+        hipStream_t st = (hipStream_t)stream;
+        if (d->ksize == 1) conv_sk_launch_k1(cfg, tw, L, st, sk);
+        else if (d->dil == 1) conv_sk_launch_k3d1(cfg, tw, L, st, sk);
+        else conv_sk_launch_k3d2(cfg, tw, L, st, sk);
+        DVC_CHECK_LAUNCH("dvc_conv2d(stream-K)");
+        return 0;
+    }
     if (cfg >= 16) {  // 16 + tile configuration: force register staging (autotuner / A-B measurements)
         cfg -= 16;
         allow_dma = false;

@@ -121,13 +121,21 @@ __host__ __device__ __forceinline__ long corr_unit_owner(long u, long U, long G)
 #define CORR_RD(r0, r1, s)                                                      \
     "ds_read_b32 %[" #r0 "], %[addr] offset:(" CORR_STR(s) ")*256\n\t"          \
     "ds_read_b32 %[" #r1 "], %[addr] offset:((" CORR_STR(s) ")+1)*256\n\t"
-#define CORR_MM(r0, r1, q0, q1)                                                 \
+// single chain: both MFMAs of a pair on the one accumulator
+#define CORR_MM1(r0, r1, q0, q1)                                                \
     "v_mfma_f32_32x32x2_f32 %[acc], %[" #r0 "], %[" #q0 "], %[acc]\n\t"         \
     "v_mfma_f32_32x32x2_f32 %[acc], %[" #r1 "], %[" #q1 "], %[acc]\n\t"
+// two chains: even channel pairs accumulate in acc, odd ones in accb (summed after the tile).  A dependent
+// MFMA that does not DIRECTLY follow its producer waits for the accumulator write-back (MI355X_MICROARCH.md:
+// +43 cycles for the first instruction slotted between two MFMAs on one accumulator); with two chains every
+// MFMA depends on the one before last, and the ds_reads / waits in between cost nothing.
+#define CORR_MM2(r0, r1, q0, q1)                                                \
+    "v_mfma_f32_32x32x2_f32 %[acc], %[" #r0 "], %[" #q0 "], %[acc]\n\t"         \
+    "v_mfma_f32_32x32x2_f32 %[accb], %[" #r1 "], %[" #q1 "], %[accb]\n\t"
 #define CORR_W2 "s_waitcnt lgkmcnt(2)\n\t"
 #define CORR_W0 "s_waitcnt lgkmcnt(0)\n\t"
 #define CORR_CHAIN_OPS(B)                                                                                   \
-    : [acc] "+v"(acc), [a0] "+v"(fa0), [a1] "+v"(fa1), [b0] "+v"(fb0), [b1] "+v"(fb1)                      \
+    : [acc] "+v"(acc), [accb] "+v"(accb), [a0] "+v"(fa0), [a1] "+v"(fa1), [b0] "+v"(fb0), [b1] "+v"(fb1)   \
     : [addr] "v"(kaddr), [q0] "v"(qreg[(B) * 16 + 0]), [q1] "v"(qreg[(B) * 16 + 1]),                       \
       [q2] "v"(qreg[(B) * 16 + 2]), [q3] "v"(qreg[(B) * 16 + 3]), [q4] "v"(qreg[(B) * 16 + 4]),            \
       [q5] "v"(qreg[(B) * 16 + 5]), [q6] "v"(qreg[(B) * 16 + 6]), [q7] "v"(qreg[(B) * 16 + 7]),            \
@@ -136,27 +144,38 @@ __host__ __device__ __forceinline__ long corr_unit_owner(long u, long U, long G)
       [q14] "v"(qreg[(B) * 16 + 14]), [q15] "v"(qreg[(B) * 16 + 15])                                       \
     : "memory"
 // blocks 0..6: every pair refills its registers with the pair four fragments later
-#define CORR_CHAIN_BLOCK(B)                                                                                 \
-    asm volatile(CORR_W2 CORR_MM(a0, a1, q0, q1) CORR_RD(a0, a1, (B) * 16 + 4)                              \
-                 CORR_W2 CORR_MM(b0, b1, q2, q3) CORR_RD(b0, b1, (B) * 16 + 6)                              \
-                 CORR_W2 CORR_MM(a0, a1, q4, q5) CORR_RD(a0, a1, (B) * 16 + 8)                              \
-                 CORR_W2 CORR_MM(b0, b1, q6, q7) CORR_RD(b0, b1, (B) * 16 + 10)                             \
-                 CORR_W2 CORR_MM(a0, a1, q8, q9) CORR_RD(a0, a1, (B) * 16 + 12)                             \
-                 CORR_W2 CORR_MM(b0, b1, q10, q11) CORR_RD(b0, b1, (B) * 16 + 14)                           \
-                 CORR_W2 CORR_MM(a0, a1, q12, q13) CORR_RD(a0, a1, (B) * 16 + 16)                           \
-                 CORR_W2 CORR_MM(b0, b1, q14, q15) CORR_RD(b0, b1, (B) * 16 + 18) CORR_CHAIN_OPS(B))
+#define CORR_CHAIN_BLOCK(MM, B)                                                                             \
+    asm volatile(CORR_W2 MM(a0, a1, q0, q1) CORR_RD(a0, a1, (B) * 16 + 4)                                   \
+                 CORR_W2 MM(b0, b1, q2, q3) CORR_RD(b0, b1, (B) * 16 + 6)                                   \
+                 CORR_W2 MM(a0, a1, q4, q5) CORR_RD(a0, a1, (B) * 16 + 8)                                   \
+                 CORR_W2 MM(b0, b1, q6, q7) CORR_RD(b0, b1, (B) * 16 + 10)                                  \
+                 CORR_W2 MM(a0, a1, q8, q9) CORR_RD(a0, a1, (B) * 16 + 12)                                  \
+                 CORR_W2 MM(b0, b1, q10, q11) CORR_RD(b0, b1, (B) * 16 + 14)                                \
+                 CORR_W2 MM(a0, a1, q12, q13) CORR_RD(a0, a1, (B) * 16 + 16)                                \
+                 CORR_W2 MM(b0, b1, q14, q15) CORR_RD(b0, b1, (B) * 16 + 18) CORR_CHAIN_OPS(B))
 // block 7: no reads past fragment 127; ends with the wait states an MFMA result needs before a VALU read
-#define CORR_CHAIN_LAST()                                                                                   \
-    asm volatile(CORR_W2 CORR_MM(a0, a1, q0, q1) CORR_RD(a0, a1, 7 * 16 + 4)                                \
-                 CORR_W2 CORR_MM(b0, b1, q2, q3) CORR_RD(b0, b1, 7 * 16 + 6)                                \
-                 CORR_W2 CORR_MM(a0, a1, q4, q5) CORR_RD(a0, a1, 7 * 16 + 8)                                \
-                 CORR_W2 CORR_MM(b0, b1, q6, q7) CORR_RD(b0, b1, 7 * 16 + 10)                               \
-                 CORR_W2 CORR_MM(a0, a1, q8, q9) CORR_RD(a0, a1, 7 * 16 + 12)                               \
-                 CORR_W2 CORR_MM(b0, b1, q10, q11) CORR_RD(b0, b1, 7 * 16 + 14)                             \
-                 CORR_W2 CORR_MM(a0, a1, q12, q13)                                                          \
-                 CORR_W0 CORR_MM(b0, b1, q14, q15) "s_nop 15\n\ts_nop 7\n\t" CORR_CHAIN_OPS(7))
+#define CORR_CHAIN_LAST(MM)                                                                                 \
+    asm volatile(CORR_W2 MM(a0, a1, q0, q1) CORR_RD(a0, a1, 7 * 16 + 4)                                     \
+                 CORR_W2 MM(b0, b1, q2, q3) CORR_RD(b0, b1, 7 * 16 + 6)                                     \
+                 CORR_W2 MM(a0, a1, q4, q5) CORR_RD(a0, a1, 7 * 16 + 8)                                     \
+                 CORR_W2 MM(b0, b1, q6, q7) CORR_RD(b0, b1, 7 * 16 + 10)                                    \
+                 CORR_W2 MM(a0, a1, q8, q9) CORR_RD(a0, a1, 7 * 16 + 12)                                    \
+                 CORR_W2 MM(b0, b1, q10, q11) CORR_RD(b0, b1, 7 * 16 + 14)                                  \
+                 CORR_W2 MM(a0, a1, q12, q13)                                                               \
+                 CORR_W0 MM(b0, b1, q14, q15) "s_nop 15\n\ts_nop 7\n\t" CORR_CHAIN_OPS(7))
+#define CORR_CHAIN_ALL(MM)                                                                                  \
+    do {                                                                                                    \
+        CORR_CHAIN_BLOCK(MM, 0);                                                                            \
+        CORR_CHAIN_BLOCK(MM, 1);                                                                            \
+        CORR_CHAIN_BLOCK(MM, 2);                                                                            \
+        CORR_CHAIN_BLOCK(MM, 3);                                                                            \
+        CORR_CHAIN_BLOCK(MM, 4);                                                                            \
+        CORR_CHAIN_BLOCK(MM, 5);                                                                            \
+        CORR_CHAIN_BLOCK(MM, 6);                                                                            \
+        CORR_CHAIN_LAST(MM);                                                                                \
+    } while (0)
 
-template <bool WTA, bool VEC4>
+template <bool WTA, bool VEC4, bool DUAL = true>
 __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     // two key tiles (double buffer, 2 x 32 KB) + three pooled-Lab tiles [3][256] (first 96 floats used).
     // Three, because with ONE barrier per iteration the pending tile's Lab (read during the chain by slow
@@ -393,9 +412,9 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
 
         // S^T tile of THIS key tile: 128 dependent MFMAs (K = 256), one basic block; the A fragments are
         // conflict-free ds_reads the scheduler is free to hoist
-        f32x16 acc;
+        f32x16 acc, accb;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = accb[r] = 0.f;
         // LDS byte address of this lane's fragment 0: A[i = l31][k = hi] of the tile in buffer `cur`
         const unsigned kaddr = (unsigned)(size_t)(AS3 float*)(smem + cur * CORR_C * CORR_KT + hi * CORR_KT + l31);
         float fa0, fa1, fb0, fb1;
@@ -403,14 +422,12 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
                      : [a0] "=&v"(fa0), [a1] "=&v"(fa1), [b0] "=&v"(fb0), [b1] "=&v"(fb1)
                      : [addr] "v"(kaddr)
                      : "memory");
-        CORR_CHAIN_BLOCK(0);
-        CORR_CHAIN_BLOCK(1);
-        CORR_CHAIN_BLOCK(2);
-        CORR_CHAIN_BLOCK(3);
-        CORR_CHAIN_BLOCK(4);
-        CORR_CHAIN_BLOCK(5);
-        CORR_CHAIN_BLOCK(6);
-        CORR_CHAIN_LAST();
+        if (DUAL) {
+            CORR_CHAIN_ALL(CORR_MM2);
+            acc += accb;   // (fixed order: the same in both passes of the WTA variant)
+        } else {
+            CORR_CHAIN_ALL(CORR_MM1);
+        }
         if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 1] = __builtin_amdgcn_s_memtime();
         if (!a.dbg_variant) process_tile(acc, t * CORR_KT, bl + ((t - t0) % 3) * 256);
         if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 2] = __builtin_amdgcn_s_memtime();
@@ -595,19 +612,27 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
     dim3 mgrid(cdiv(P, 64), B);
     static_assert(CORR_QB % 64 == 0, "merge kernel assumes one query block per 64-query workgroup");
     const bool wta = wta_scale != 1.0f;
+    const bool single = g_corr_dbg_variant == 2;   // debug only: the single-accumulator chain (A/B measurements)
+    if (single) a.dbg_variant = 0;
+    auto launch = [&](bool wta_pass) {
+        if (single) {
+            if (wta_pass) { if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<true, true, false>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((corr_fwd_kernel<true, false, false>), grid, dim3(256), 0, s, a); }
+            else { if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<false, true, false>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((corr_fwd_kernel<false, false, false>), grid, dim3(256), 0, s, a); }
+        } else {
+            if (wta_pass) { if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<true, true, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((corr_fwd_kernel<true, false, true>), grid, dim3(256), 0, s, a); }
+            else { if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<false, true, true>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((corr_fwd_kernel<false, false, true>), grid, dim3(256), 0, s, a); }
+        }
+    };
     if (wta) {
         // pass 1: row maxima only (identical MFMA order => `f == rowmax` is exact in pass 2)
-        if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((corr_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
+        launch(false);
         DVC_CHECK_LAUNCH("dvc_corr_fwd(pass1)");
         hipLaunchKernelGGL(corr_merge_kernel, mgrid, dim3(256), 0, s, a.part, a.nslot, P, pl.nqb, pl.ntiles, pl.U,
                            pl.G, h, w, (float*)nullptr, fmax_buf, (float*)nullptr, (float*)nullptr, (int*)nullptr);
         DVC_CHECK_LAUNCH("dvc_corr_fwd(merge1)");
-        if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((corr_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
+        launch(true);
     } else {
-        if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((corr_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
+        launch(false);
     }
     DVC_CHECK_LAUNCH("dvc_corr_fwd");
     hipLaunchKernelGGL(corr_merge_kernel, mgrid, dim3(256), 0, s, a.part, a.nslot, P, pl.nqb, pl.ntiles, pl.U, pl.G,

@@ -203,7 +203,7 @@ class ClipColorizer:
         return outs
 
     def clip_rgb(self, frames_lab_large, wls_filter_on=True, lambda_value=500, sigma_color=4, frame_propagate=False,
-                 lookahead=2, tail_batch=4):
+                 lookahead=2, tail_batch=4, last=None):
         """The device-side part of the whole per-frame loop of test.py:68-116: full-resolution Lab frames
         (what `transform(...)` yields, test.py:70) -> x0.5 bilinear -> frame_colorization recurrence -> x2
         bilinear * 1.25 -> WLS filter -> 8-bit RGB (H x W x 3 uint8 device tensors, one per frame).
@@ -239,14 +239,14 @@ class ClipColorizer:
             if len(pending) >= tail_batch or t == len(small) - 1:
                 flush()
 
-        self.clip(small, frame_propagate=frame_propagate, lookahead=lookahead, on_frame=on_frame)
+        self.clip(small, frame_propagate=frame_propagate, last=last, lookahead=lookahead, on_frame=on_frame)
         caller.wait_stream(ts)
         for x in rgbs:
             x.record_stream(caller)
         return rgbs
 
     def colorize_video(self, frames_rgb8, reference_rgb8=None, image_size=(432, 768), wls_filter_on=True,
-                       lambda_value=500, sigma_color=4, frame_propagate=False):
+                       lambda_value=500, sigma_color=4, frame_propagate=False, continue_clip=False):
         """colorize_video of test.py:29-121 without its file I/O: 8-bit RGB device frames (any size) in, 8-bit RGB
         colourised frames (image_size) out.  `image_size` is the size CenterPad produces (twice the network
         resolution; the reference's --image_size is the network resolution and test.py:163 doubles it).
@@ -254,6 +254,11 @@ class ClipColorizer:
         test.py:50 ignores `reference_file` in that mode."""
         from . import tail
         large = [tail.frame_ingest(f, image_size) for f in frames_rgb8]
+        if continue_clip:
+            # next batch of frames of the SAME clip: keep the exemplar, continue the recurrence (test.py:96)
+            if self.IB_lab is None or self.last_lab is None:
+                raise RuntimeError("colorize_video(continue_clip=True) needs a previous call on this clip")
+            return self.clip_rgb(large, wls_filter_on, lambda_value, sigma_color, last=self.last_lab)
         if not frame_propagate and reference_rgb8 is None:
             raise ValueError("colorize_video: reference_rgb8 is required unless frame_propagate=True")
         ref_large = large[0] if frame_propagate else tail.frame_ingest(reference_rgb8, image_size)

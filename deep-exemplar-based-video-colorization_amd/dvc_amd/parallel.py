@@ -53,7 +53,8 @@ def broadcast_exemplar(cc, IB_lab, shape, device, src=0):
     else:
         bufs = [torch.empty(s, device=device, dtype=dt) for s, dt in cc.exemplar_cache_spec(shape)]
     for b in bufs:
-        dist.broadcast(b, src)
+        # as raw bytes: RCCL has no int16 (the bf16 bit patterns of the candidate-filter cache)
+        dist.broadcast(b.view(torch.uint8) if b.dtype not in (torch.float32, torch.uint8) else b, src)
     if rank != src:
         cc.load_exemplar_cache(IB, bufs)
 

@@ -92,6 +92,9 @@ CONTRACTIVE_OUT_GAIN = 0.04
 # 1000..1011 have a row below 2e-6, where fp32 rounding — ~3e-7 on an affinity — decides the arg-max and
 # the reference itself flips with its thread count).
 WELL_SEPARATED_FRAME_SEEDS_216x384 = (1000, 1003, 1006, 1009)
+# same criterion at 432x768 (20736 rows): seed 1001 (smallest gap 2.7e-6; 13 of the 14 seeds 1000..1013 have a row
+# below 2e-6)
+WELL_SEPARATED_FRAME_SEED_432x768 = 1001
 
 
 def synth_lab(seed, H=216, W=384):

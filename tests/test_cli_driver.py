@@ -1,0 +1,130 @@
+"""The test.py-shaped clip driver (dvc_amd/cli.py; /root/reference/test.py:29-186): host logic on CPU, the whole
+loop on the GPU with synthetic frames written to a temporary folder."""
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+
+def _parse_avi(path):
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"AVI "
+    assert struct.unpack("<I", raw[4:8])[0] == len(raw) - 8
+    n_frames = struct.unpack("<I", raw[raw.index(b"avih") + 8 + 16:raw.index(b"avih") + 8 + 20])[0]
+    us_per_frame = struct.unpack("<I", raw[raw.index(b"avih") + 8:raw.index(b"avih") + 12])[0]
+    assert b"MJPG" in raw[:300]
+    movi = raw.index(b"movi")
+    idx = raw.index(b"idx1", movi)
+    n_idx = struct.unpack("<I", raw[idx + 4:idx + 8])[0] // 16
+    frames = []
+    for i in range(n_idx):
+        tag, flags, off, size = struct.unpack("<4sIII", raw[idx + 8 + 16 * i:idx + 24 + 16 * i])
+        start = movi + off          # offsets are relative to the 'movi' fourcc
+        assert raw[start:start + 4] == b"00dc" and struct.unpack("<I", raw[start + 4:start + 8])[0] == size
+        frames.append(raw[start + 8:start + 8 + size])
+    return n_frames, us_per_frame, frames
+
+
+def test_cli_host_logic(tmp_path):
+    from PIL import Image
+    from dvc_amd import cli
+    # the upstream flags with their quirks (test.py:127-135)
+    p = cli.build_parser()
+    o = p.parse_args([])
+    assert o.frame_propagate is False and o.image_size == [432, 768] and o.cuda is True and o.gpu_ids == "0"
+    assert o.clip_path == "./sample_videos/clips/v32" and o.ref_path == "./sample_videos/ref/v32"
+    assert p.parse_args(["--frame_propagate", "False"]).frame_propagate is True      # type=bool quirk, kept
+    assert p.parse_args(["--image_size", "216"]).image_size == 216                  # single int, as upstream
+    assert p.parse_args(["--cuda"]).cuda is False
+    # numeric file order (test.py:41)
+    names = ["10.png", "9.png", "frame_100.png", "2.png"]
+    names.sort(key=lambda f: int("".join(filter(str.isdigit, f) or -1)))
+    assert names == ["2.png", "9.png", "10.png", "frame_100.png"]
+    # save_frames naming + folder2vid (MJPG AVI at 24 fps when OpenCV is absent)
+    out = tmp_path / "o"
+    cli.mkdir_if_not(str(out))
+    cli.mkdir_if_not(str(out))
+    rng = np.random.default_rng(0)
+    for i in range(3):
+        cli.save_frames(rng.integers(0, 255, (36, 64, 3)).astype(np.float64), str(out), i)
+    assert sorted(os.listdir(out)) == ["00000.jpg", "00001.jpg", "00002.jpg"]
+    cli.folder2vid(str(out), str(out), "video.avi")
+    n, us, frames = _parse_avi(str(out / "video.avi"))
+    assert n == 3 and len(frames) == 3 and us == int(1e6 / 24)
+    import io
+    assert Image.open(io.BytesIO(frames[1])).size == (64, 36)
+    with pytest.raises(ValueError):
+        Image.fromarray(np.zeros((8, 8), np.uint8)).save(str(tmp_path / "g.png"))
+        cli._load_rgb8(str(tmp_path / "g.png"), torch.device("cpu"))
+
+
+def _smooth_rgb(seed, h, w):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand(1, 3, max(h // 16, 2), max(w // 16, 2), generator=g)
+    x = torch.nn.functional.interpolate(base, (h, w), mode="bilinear", align_corners=False)
+    return (x[0].permute(1, 2, 0) * 255).round().clamp(0, 255).to(torch.uint8).numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frame_propagate", [False, True])
+def test_colorize_video_end_to_end(tmp_path, frame_propagate, monkeypatch):
+    """colorize_video(opt, ...) on a folder of PNG frames: numeric order, exemplar choice, batching that continues
+    the recurrence, files written; the saved arrays equal ClipColorizer.colorize_video on the same frames."""
+    import contextlib
+    import io
+    from PIL import Image
+    from dvc_amd import cli, synth
+    from dvc_amd.frame import ClipColorizer
+    from models.ColorVidNet import ColorVidNet
+    from models.NonlocalNet import VGG19_pytorch, WarpNet
+    clip = tmp_path / "clips" / "c1"
+    os.makedirs(clip)
+    H0, W0, n = 180, 320, 5
+    order = [3, 10, 1, 22, 7]                      # file numbers, NOT in lexicographic order
+    imgs = {}
+    for k, num in enumerate(order):
+        imgs[num] = _smooth_rgb(100 + k, H0, W0)
+        Image.fromarray(imgs[num]).save(str(clip / f"{num}.png"))
+    ref = _smooth_rgb(7, 200, 300)
+    Image.fromarray(ref).save(str(tmp_path / "ref.png"))
+    sd = (synth.vgg19_state_dict(0), synth.warpnet_state_dict(0), synth.colorvidnet_state_dict(0, contractive=True))
+    with contextlib.redirect_stdout(io.StringIO()):
+        nets = (VGG19_pytorch(), WarpNet(1), ColorVidNet(7))
+    for m, s in zip(nets, sd):
+        m.load_state_dict(s)
+        m.eval().cuda()
+    vgg, warp, col = nets
+    saved = {}
+    real_save = cli.save_frames
+
+    def spy(image, folder, index=None, image_name=None):
+        saved.setdefault(folder, []).append(np.array(image))
+        real_save(image, folder, index, image_name)
+
+    monkeypatch.setattr(cli, "save_frames", spy)
+    size = [96, 160]                                   # full-resolution size; the networks run at 48 x 80
+    outs = {}
+    for batch in (2, 32):
+        opt = cli.build_parser().parse_args(["--frame_propagate", "1"] if frame_propagate else [])
+        opt.image_size, opt.batch_frames = size, batch
+        out = str(tmp_path / f"out_b{batch}_{int(frame_propagate)}")
+        cli.colorize_video(opt, str(clip) + "/", str(tmp_path / "ref.png"), out, warp, col, vgg)
+        files = sorted(os.listdir(out))
+        assert files == [f"{i:05d}.jpg" for i in range(n)] + ["video.avi"]
+        nf, _, _ = _parse_avi(os.path.join(out, "video.avi"))
+        assert nf == n
+        outs[batch] = saved[out]
+        assert Image.open(os.path.join(out, "00000.jpg")).size == (size[1], size[0])
+    for a, b in zip(outs[2], outs[32]):              # batching continues the recurrence: identical frames
+        assert np.array_equal(a, b)
+    cc = ClipColorizer(vgg, warp, col, temperature=1e-10)
+    dev = [torch.from_numpy(imgs[num]).cuda() for num in sorted(order)]
+    want = cc.colorize_video(dev, None if frame_propagate else torch.from_numpy(ref).cuda(), image_size=size,
+                             frame_propagate=frame_propagate)
+    for a, w in zip(outs[32], want):
+        assert np.array_equal(a, w.cpu().numpy())
+    if not frame_propagate:                            # the exemplar matters: another reference, other colours
+        other = cc.colorize_video(dev, torch.from_numpy(_smooth_rgb(8, 200, 300)).cuda(), image_size=size)
+        assert not np.array_equal(other[0].cpu().numpy(), outs[32][0])

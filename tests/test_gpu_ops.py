@@ -150,6 +150,59 @@ def test_conv2d_split_k(ops, split_k):
     assert (big[:, :8] == 3).all() and (big[:, 72:] == 3).all()
 
 
+SK_CASES = [
+    # name, N, Cin, Cout, H, W, ks, dil, pad, pad_mode, in_up, in_sub, res, act   (plain layers: the stream-K path)
+    ("sk_up_res", 1, 32, 64, 13, 24, 3, 1, 1, 0, 2, 1, True, 1),
+    ("sk_sub", 1, 16, 64, 54, 96, 3, 1, 1, 0, 1, 2, False, 1),
+    ("sk_dil2_b2", 2, 32, 64, 27, 48, 3, 2, 2, 0, 1, 1, False, 1),
+    ("sk_wide", 1, 24, 128, 21, 100, 3, 1, 1, 0, 1, 1, False, 3),
+    ("sk_k1", 1, 64, 64, 31, 17, 1, 1, 0, 0, 1, 1, True, 0),
+    ("sk_reflect", 1, 64, 128, 30, 40, 3, 1, 1, 1, 1, 1, False, 0),
+    ("sk_one_chunk", 2, 8, 64, 20, 36, 3, 1, 1, 0, 1, 1, True, 1),       # NC = 1: every unit is a whole tile
+    # network shapes: ranges of ~20-40 units crossing tile boundaries, every flush kind
+    ("sk_res_trunk", 1, 256, 256, 54, 96, 3, 1, 1, 1, 1, 1, False, 0),
+    ("sk_vgg5", 1, 512, 512, 13, 24, 3, 1, 1, 0, 1, 1, False, 1),
+    ("sk_cvn_d2", 1, 512, 512, 27, 48, 3, 2, 2, 0, 1, 1, False, 1),
+    ("sk_cvn_up", 1, 256, 128, 54, 96, 3, 1, 1, 0, 2, 1, True, 1),
+    ("sk_full_res", 1, 64, 64, 216, 384, 3, 1, 1, 0, 1, 1, False, 1),
+    ("sk_theta", 1, 256, 256, 54, 96, 1, 1, 0, 0, 1, 1, False, 0),
+]
+
+
+@pytest.mark.parametrize("case", SK_CASES, ids=[c[0] for c in SK_CASES])
+@pytest.mark.parametrize("cfg,per_cu", [(36, 2), (36, 1), (35, 2), (34, 2), (33, 2), (32, 2), (32, 1), (37, 2), (37, 1), (38, 2)])
+def test_conv2d_stream_k(ops, case, cfg, per_cu):
+    """Stream-K decomposition (cfg = 32 + tile configuration; equal unit ranges per workgroup, partial tiles through
+    slots + fixed-order fixup): same result as the fp64 reference at the engine's tolerance, deterministic, destination
+    may be a channel slice, and the bytes around the destination stay untouched."""
+    (name, N, Cin, Cout, H, W, ks, dil, pad, pad_mode, in_up, in_sub, use_res, act) = case
+    mt = {32: 64, 33: 32, 34: 64, 35: 32, 36: 64, 37: 64, 38: 32}[cfg]      # 37 / 38: 36 / 35 with two accumulator chains
+    if Cout % mt:
+        pytest.skip("Cout not a multiple of the configuration's channel tile")
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    OH, OW = ops.conv_out_hw(H, W, ks, 1, dil, pad, in_up, in_sub)
+    res = torch.randn(N, Cout, OH, OW, generator=g) if use_res else None
+    ref = ref_conv(x, w, b, ks, 1, dil, pad, pad_mode, in_up, in_sub, None, None, None, res, act, 0.2)
+    big = torch.full((N, Cout + 16, OH, OW), 3.0, device="cuda")
+    kw = dict(ksize=ks, dil=dil, pad=pad, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, act=act, act_slope=0.2,
+              residual=None if res is None else res.cuda(), out=big[:, 8:8 + Cout],
+              out_batch_stride=(Cout + 16) * OH * OW, cfg=cfg, split_k=per_cu)
+    xd, wd, bd = x.cuda(), ops.pack_conv_weight(w.cuda()), b.cuda()
+    ops.conv2d(xd, wd, bd, **kw)
+    y1 = big[:, 8:8 + Cout].clone()
+    big[:, 8:8 + Cout] = -7.0
+    ops.conv2d(xd, wd, bd, **kw)
+    torch.cuda.synchronize()
+    e = relerr(y1, ref)
+    report(f"conv2d stream-K {name} cfg={cfg} per_cu={per_cu}: rel_err={e:.3e}")
+    assert e < 2e-5, (name, cfg, per_cu, e)
+    assert torch.equal(y1, big[:, 8:8 + Cout])               # deterministic, every element rewritten
+    assert (big[:, :8] == 3).all() and (big[:, 8 + Cout:] == 3).all()
+
+
 def test_conv2d_channel_slice_output(ops):
     """y may be a channel slice of a wider tensor (WarpNet concat, NonlocalNet.py:464)."""
     g = torch.Generator().manual_seed(5)
