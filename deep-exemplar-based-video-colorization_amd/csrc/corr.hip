@@ -175,7 +175,7 @@ __host__ __device__ __forceinline__ long corr_unit_owner(long u, long U, long G)
         CORR_CHAIN_LAST(MM);                                                                                \
     } while (0)
 
-template <bool WTA, bool VEC4, bool DUAL = true>
+template <bool WTA, bool VEC4, bool DUAL = false>
 __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     // two key tiles (double buffer, 2 x 32 KB) + three pooled-Lab tiles [3][256] (first 96 floats used).
     // Three, because with ONE barrier per iteration the pending tile's Lab (read during the chain by slow
@@ -195,6 +195,11 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     const long wlog = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
     long u = corr_unit_start(wlog, a.U, G);
     const long u_end = corr_unit_start(wlog + 1, a.U, G);
+    if (a.dbg_variant == 3 && (long)(blockIdx.x / 8) >= G / 16) {
+        // timing experiment: start the second workgroup of every CU half a key tile late, so that one wave's softmax
+        // block falls into its SIMD partner's MFMA chain instead of into the partner's own softmax block
+        __builtin_amdgcn_s_sleep(127);
+    }
     long long* dbgh = nullptr;  // debug header slot: [entry, loop start, loop end, exit] of the first segment
     if (a.dbg && tid == 0) {
         dbgh = a.dbg + ((long)blockIdx.x * a.dbg_tiles + (a.dbg_tiles - 1)) * 4;
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
             CORR_CHAIN_ALL(CORR_MM1);
         }
         if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 1] = __builtin_amdgcn_s_memtime();
-        if (!a.dbg_variant) process_tile(acc, t * CORR_KT, bl + ((t - t0) % 3) * 256);
+        if (a.dbg_variant != 1) process_tile(acc, t * CORR_KT, bl + ((t - t0) % 3) * 256);
         if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 2] = __builtin_amdgcn_s_memtime();
         commit(cur ^ 1, (t + 1 - t0) % 3);
         __syncthreads();  // next tile landed (DMA drained / stores visible); this tile's reads done
@@ -612,8 +617,8 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
     dim3 mgrid(cdiv(P, 64), B);
     static_assert(CORR_QB % 64 == 0, "merge kernel assumes one query block per 64-query workgroup");
     const bool wta = wta_scale != 1.0f;
-    const bool single = g_corr_dbg_variant == 2;   // debug only: the single-accumulator chain (A/B measurements)
-    if (single) a.dbg_variant = 0;
+    const bool single = g_corr_dbg_variant != 2;   // debug variant 2: the two-accumulator chain (A/B measurements: slower)
+    if (!single) a.dbg_variant = 0;
     auto launch = [&](bool wta_pass) {
         if (single) {
             if (wta_pass) { if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<true, true, false>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((corr_fwd_kernel<true, false, false>), grid, dim3(256), 0, s, a); }

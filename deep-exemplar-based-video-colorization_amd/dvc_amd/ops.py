@@ -156,6 +156,7 @@ if _autotune:
 
 # split-K candidates of the autotuner (DVC_TUNE_SPLITS=1 disables split-K: experiments only)
 _TUNE_SPLITS = tuple(int(v) for v in _os.environ.get("DVC_TUNE_SPLITS", "1,2,3,4,6,8").split(","))
+_TUNE_STREAMK = tuple((int(a), int(b)) for a, b in (v.split(":") for v in _os.environ.get("DVC_TUNE_STREAMK", "41:2,41:1").split(",") if v))
 
 
 def _tune_conv(lib, d, tensors):
@@ -171,6 +172,16 @@ def _tune_conv(lib, d, tensors):
 
     best, best_t = (-1, 0), float("inf")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def time_it():
+        launch()
+        e0.record()
+        for _ in range(3):
+            launch()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
     # (layers without a fused input transform stage through LDS-DMA; forcing register staging, cfg 16 + k,
     # never won in the per-layer sweep, so it is not a candidate)
     for cfg in (0, 1, 2, 3, 4):
@@ -178,15 +189,18 @@ def _tune_conv(lib, d, tensors):
             d.cfg, d.split_k = cfg, sk
             if launch() != 0:          # configuration does not fit this geometry
                 break
-            launch()
-            e0.record()
-            for _ in range(3):
-                launch()
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
+            t = time_it()
             if t < best_t:
                 best, best_t = (cfg, sk), t
+    # stream-K decomposition (plain stride-1 layers only; the call fails cleanly otherwise): 64x64 tiles with
+    # buffer-descriptor staging, 1 or 2 workgroups per CU
+    for cfg, per_cu in _TUNE_STREAMK:
+        d.cfg, d.split_k = cfg, per_cu
+        if launch() != 0:
+            continue
+        t = time_it()
+        if t < best_t:
+            best, best_t = (cfg, per_cu), t
     d.cfg, d.split_k = best
     return best
 

@@ -64,7 +64,7 @@ def _smooth_rgb(seed, h, w):
     g = torch.Generator().manual_seed(seed)
     base = torch.rand(1, 3, max(h // 16, 2), max(w // 16, 2), generator=g)
     x = torch.nn.functional.interpolate(base, (h, w), mode="bilinear", align_corners=False)
-    return (x[0].permute(1, 2, 0) * 255).round().clamp(0, 255).to(torch.uint8).numpy()
+    return np.ascontiguousarray((x[0].permute(1, 2, 0) * 255).round().clamp(0, 255).to(torch.uint8).numpy())
 
 
 @pytest.mark.gpu

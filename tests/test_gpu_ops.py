@@ -170,15 +170,20 @@ SK_CASES = [
 
 
 @pytest.mark.parametrize("case", SK_CASES, ids=[c[0] for c in SK_CASES])
-@pytest.mark.parametrize("cfg,per_cu", [(36, 2), (36, 1), (35, 2), (34, 2), (33, 2), (32, 2), (32, 1), (37, 2), (37, 1), (38, 2)])
+@pytest.mark.parametrize("cfg,per_cu", [(36, 2), (36, 1), (35, 2), (34, 2), (33, 2), (32, 2), (32, 1), (37, 2), (37, 1), (38, 2),
+                                         (39, 2), (39, 1), (40, 2), (41, 2), (41, 1), (42, 2), (43, 2), (44, 2), (45, 2), (45, 1), (54, 2), (54, 1), (55, 1)])
 def test_conv2d_stream_k(ops, case, cfg, per_cu):
     """Stream-K decomposition (cfg = 32 + tile configuration; equal unit ranges per workgroup, partial tiles through
     slots + fixed-order fixup): same result as the fp64 reference at the engine's tolerance, deterministic, destination
     may be a channel slice, and the bytes around the destination stay untouched."""
     (name, N, Cin, Cout, H, W, ks, dil, pad, pad_mode, in_up, in_sub, use_res, act) = case
-    mt = {32: 64, 33: 32, 34: 64, 35: 32, 36: 64, 37: 64, 38: 32}[cfg]      # 37 / 38: 36 / 35 with two accumulator chains
+    mt = {32: 64, 33: 32, 34: 64, 35: 32, 36: 64, 37: 64, 38: 32, 39: 64, 40: 32, 41: 64, 42: 64, 43: 32, 44: 64, 45: 64, 54: 32, 55: 64}[cfg]
+    # 37 / 38: 36 / 35 with two accumulator chains; 39 / 40: 36 / 35 with register-pipelined operands;
+    # 41..45: buffer-descriptor staging (36, 36 + pipelined, 35, 34, 32)
     if Cout % mt:
         pytest.skip("Cout not a multiple of the configuration's channel tile")
+    if cfg >= 54 and Cin % (16 if ks == 3 else 32):
+        pytest.skip("Cin not a multiple of the double-length chunk")
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5

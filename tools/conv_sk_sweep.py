@@ -74,7 +74,7 @@ for k, (r, count) in uniq.items():
     run(-1)
     ref = out.clone()
     plain = not r["affine"] and not r["in_prelu"] and r["stride"] == 1 and r["Cin"] % (8 if r["ksize"] == 3 else 16) == 0
-    for cfg in (0, 2, 3, 4):
+    for cfg in (4,):
         for skk in (1, 2, 3, 4):
             try:
                 times[f"old{cfg}/s{skk}"] = timeit(lambda: run(cfg, skk))
@@ -82,7 +82,7 @@ for k, (r, count) in uniq.items():
                 pass
     err = {}
     if plain:
-        for cfg in (32, 33, 34, 35, 36, 37, 38):
+        for cfg in (36, 39, 41, 42, 43, 44, 45):
             for per_cu in (1, 2):
                 try:
                     times[f"sk{cfg - 32}/w{per_cu}"] = timeit(lambda: run(cfg, per_cu))
