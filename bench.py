@@ -349,9 +349,11 @@ def main():
         else:   # (--no-exemplar-cache / bf16 cache layout: rebuild the fp32 exemplar side for this leg)
             ph, bl4 = warp.exemplar_side(cc.IB_lab, *[feature_normalize(t) for t in cc.features_B[1:]], bf16=False)
         bl = bl4.view(1, 3, -1)
-        for _ in range(3):
+        # warm-up: the first milliseconds after the clip run at a lower clock (measured: 148 us vs 129 us per launch once the
+        # correlation alone has run for ~10 ms — tools/corr_ab_probe.py times round-robin for the same reason)
+        for _ in range(100 if P <= 6000 else 10):
             ops.corr_fwd(th, ph, bl, 1e-10, H // 4, W // 4)
-        reps = 30
+        reps = 50 if P <= 6000 else 10
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                      # ops launch on torch's current stream, so these events see them
         for _ in range(reps):
