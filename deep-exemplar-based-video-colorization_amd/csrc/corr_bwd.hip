@@ -1,0 +1,91 @@
+// Backward of the fused correlation for the training-side callers (train.py:402-427 runs frame_colorization with
+// autograd on, soft temperature 0.01): gradients of
+//     f = theta^T phi,  p = softmax_j(f / T),  y = p . B_lab,  sim = max_j f          (models/NonlocalNet.py:477-500)
+// with respect to theta and phi.  As in the forward pass the P x P matrices never exist: the host walks the query rows
+// in blocks of R rows; per block
+//     F  = theta_blk^T phi                    R x P   (1x1 convolution engine)
+//     dS = p * (g . B_j - g . y_i) / T  (+ the sim gradient at the row arg-max),  p = exp(F/T - m_i) / l_i     [here]
+//     d theta_blk = phi dS^T,   d phi += theta_blk dS                              (1x1 convolution engine)
+// This file holds the two bandwidth-bound kernels of the middle step: the row sums l_i, and dS written in both
+// layouts (row-major for d phi, transposed for d theta — the engine wants K-major operands).
+#include "common.h"
+
+#include <cmath>
+
+// l_i = sum_j exp(fl32(F_ij / T) - m_i),  m_i = fl32(sim_i / T): ATen's softmax arithmetic (true division, exp of the
+// difference to the row maximum), one workgroup per row.
+__global__ __launch_bounds__(256) void corr_bwd_rowsum_kernel(const float* __restrict__ F, const float* __restrict__ sim,
+                                                              float T, int P, float* __restrict__ l_out) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const float* f = F + (long)row * P;
+    const float m = sim[row] / T;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < P; j += 256) s += expf(f[j] / T - m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) l_out[row] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dS tile 64 rows x 64 columns: computed once, written row-major (coalesced along j) and, through an LDS transpose,
+// column-major (coalesced along i).
+__global__ __launch_bounds__(256) void corr_bwd_ds_kernel(const float* __restrict__ F, const float* __restrict__ blab,
+                                                          const float* __restrict__ gy, const float* __restrict__ y,
+                                                          const float* __restrict__ sim, const float* __restrict__ gsim,
+                                                          const int* __restrict__ amax, const float* __restrict__ lsum,
+                                                          float T, int rows, int P, long cs, int ldt,
+                                                          float* __restrict__ dS, float* __restrict__ dST) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int j = j0 + tx;
+    const bool jok = j < P;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    if (jok) {
+        b0 = blab[j];
+        b1 = blab[(long)P + j];
+        b2 = blab[2L * P + j];
+    }
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int il = ty * 16 + r, i = i0 + il;
+        float v = 0.f;
+        if (i < rows && jok) {
+            const float g0 = gy[i], g1 = gy[cs + i], g2 = gy[2 * cs + i];
+            const float delta = g0 * y[i] + g1 * y[cs + i] + g2 * y[2 * cs + i];
+            const float m = sim[i] / T;
+            const float p = expf(F[(long)i * P + j] / T - m) / lsum[i];
+            v = p * ((g0 * b0 + g1 * b1 + g2 * b2) - delta) / T;
+            if (gsim && amax[i] == j) v += gsim[i];
+            dS[(long)i * P + j] = v;
+        }
+        tile[il][tx] = v;
+    }
+    __syncthreads();
+    // transposed copy: thread (tx -> row i0 + tx, ty -> 16 columns)
+    const int i = i0 + tx;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int jl = ty * 16 + r, jj = j0 + jl;
+        if (jj < P && i < ldt) dST[(long)jj * ldt + i] = (i < rows) ? tile[tx][jl] : 0.f;
+    }
+}
+
+extern "C" int dvc_corr_softmax_bwd(const float* f_blk, const float* blab, const float* gy, const float* y,
+                                    const float* sim, const float* gsim, const int32_t* argmax, float temperature,
+                                    int32_t rows, int32_t P, int64_t chan_stride, int32_t ld_t, float* lsum_scratch,
+                                    float* dS, float* dST, dvcStream stream) {
+    DVC_REQUIRE(f_blk && blab && gy && y && sim && lsum_scratch && dS && dST, "dvc_corr_softmax_bwd: null argument");
+    DVC_REQUIRE(rows > 0 && P > 0 && ld_t >= rows, "dvc_corr_softmax_bwd: bad shape");
+    DVC_REQUIRE(temperature > 0.f && std::isfinite(temperature), "dvc_corr_softmax_bwd: temperature must be > 0");
+    DVC_REQUIRE((gsim == nullptr) == (argmax == nullptr), "dvc_corr_softmax_bwd: gsim and argmax come together");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(corr_bwd_rowsum_kernel, dim3(rows), dim3(256), 0, s, f_blk, sim, temperature, P, lsum_scratch);
+    DVC_CHECK_LAUNCH("dvc_corr_softmax_bwd(rowsum)");
+    hipLaunchKernelGGL(corr_bwd_ds_kernel, dim3(cdiv(P, 64), cdiv(ld_t, 64)), dim3(256), 0, s, f_blk, blab, gy, y, sim, gsim,
+                       argmax, lsum_scratch, temperature, rows, P, (long)chan_stride, ld_t, dS, dST);
+    DVC_CHECK_LAUNCH("dvc_corr_softmax_bwd(dS)");
+    return 0;
+}

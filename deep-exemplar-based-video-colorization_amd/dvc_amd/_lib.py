@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvc_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -65,6 +65,8 @@ SIGNATURES = {
     "dvc_corr_bf16_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "dvc_corr_fwd_bf16": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,
                                          _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_size_t, _VP]),
+    "dvc_corr_softmax_bwd": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i64, c_i32,
+                                            _VP, _VP, _VP, _VP]),
 }
 
 _lib = None

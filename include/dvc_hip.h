@@ -27,7 +27,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 4
+#define DVC_ABI_VERSION 5
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -240,6 +240,21 @@ int dvc_corr_fwd_bf16(const void* theta_bf16_pc, const void* phi_bf16_pc, const 
                       const float* phi_f32_pc, const float* blab, float temperature, int32_t B, int32_t C,
                       int32_t h, int32_t w, float* y_small, float* sim_small, float* y_up, float* sim_up,
                       int32_t* argmax, void* workspace, size_t workspace_bytes, dvcStream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the fused correlation (training-side callers: train.py:402-427 runs frame_colorization, hence
+ * WarpNet.forward, models/NonlocalNet.py:477-500, under autograd at temperature 0.01).  The host walks the query rows
+ * in blocks (dvc_amd/corr_autograd.py); for one block of `rows` queries this entry turns the block's affinities
+ * f_blk[rows][P] (= theta_blk^T phi, produced by dvc_conv2d as a 1x1 convolution) into
+ *     dS[i][j] = p_ij * (g_i . B_j - g_i . y_i) / T  (+ gsim[i] at j == argmax[i]),   p = softmax_j(f / T)
+ * written row-major (dS[rows][P]) and transposed (dST[P][ld_t], rows >= `rows` zero-filled) — the two K-major operands
+ * of the 1x1-convolution GEMMs that follow (d phi += theta_blk dS, d theta_blk = phi dS^T).
+ * gy, y: [3][.] with `chan_stride` elements between channels, already offset to the block's first query; sim, gsim,
+ * argmax likewise (gsim / argmax may both be NULL: no gradient through the similarity map).  lsum_scratch: [rows]. */
+int dvc_corr_softmax_bwd(const float* f_blk, const float* blab, const float* gy, const float* y, const float* sim,
+                         const float* gsim, const int32_t* argmax, float temperature, int32_t rows, int32_t P,
+                         int64_t chan_stride, int32_t ld_t, float* lsum_scratch, float* dS, float* dST,
+                         dvcStream stream);
 
 #ifdef __cplusplus
 }
