@@ -145,8 +145,17 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 // matrix fp32 peaks are the same number), so every staging VALU instruction is taken from the MFMA rate.
 // The LDS patch image is then linear in the staged element index (pitch padding included); cells that
 // read padding zeros are zeroed once and never written again (their lanes are masked off in the DMA).
+// Waves per SIMD the variant is register-allocated for: 3 workgroups/CU for the one-tile-per-wave LDS-DMA variants
+// (2 for the dilated 32-wide one, whose patch is larger), 1 for the register-staging variants with several tiles per wave
+// and a narrow pixel tile (their staging registers do not fit twice), 2 otherwise — what each variant actually reaches.
+__host__ __device__ constexpr int conv_min_waves(int rmrn, int tw, int dil, bool gen, bool dma) {
+    if (dma && rmrn == 1) return (dil == 2 && tw == 32) ? 2 : CONV_DMA_OCC;
+    if (!dma && !gen && rmrn > 1 && tw < 32) return 1;
+    return 2;
+}
+
 template <int WM, int WN, int RM, int RN, int TW, int KS, int DIL, bool GEN, bool DMA = false>
-__global__ __launch_bounds__(64 * WM * WN, (DMA && RM * RN == 1) ? CONV_DMA_OCC : 2) void conv_mfma_kernel(ConvKArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, conv_min_waves(RM * RN, TW, DIL, GEN, DMA)) void conv_mfma_kernel(ConvKArgs a) {
     static_assert(!(GEN && DMA), "LDS-DMA staging needs compile-time geometry");
     constexpr int NT = 64 * WM * WN;
     constexpr int MT = 32 * WM * RM;

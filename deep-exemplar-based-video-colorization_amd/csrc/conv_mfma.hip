@@ -152,22 +152,17 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     int cfg = d->cfg;
     bool allow_dma = true;
     if (cfg >= 32) {
-        // 32 + tile configuration: stream-K decomposition (conv_sk_kernel.h); split_k = workgroups per CU (0 -> 2)
+        // 32 + tile configuration (2, 3 or 4): stream-K decomposition (conv_sk_kernel.h); split_k = workgroups per CU (0 -> 2)
         cfg -= 32;
-        DVC_REQUIRE(cfg < 24, "dvc_conv2d: cfg out of range");
-        // 5 / 6: tile configurations 4 / 3 with two independent accumulator chains per tile; 7 / 8: configurations
-        // 4 / 3 with the operands pipelined through registers; 9..13: buffer-descriptor staging (4, 4 + pipelined, 3, 2, 0)
-        static const int base_cfg[24] = {0, 1, 2, 3, 4, 4, 3, 4, 3, 4, 4, 3, 2, 0, 4, 4, 4, 4, 4, 4, 4, 4, 3, 4};   // (15..21: timing experiments)
-        const int ckm = cfg >= 22 ? 2 : 1;   // 22 / 23: configurations 3 / 4, buffer staging, double-length LDS chunks
-        if (cfg >= 9)
-            DVC_REQUIRE((long)d->Cin * d->H * d->W * 4 < (1L << 31) && (long)d->Cin * d->ksize * d->ksize * d->Cout * 4 < (1L << 31),
-                        "dvc_conv2d: tensor too large for buffer-descriptor staging");
-        const ConvCfg& c = kConvCfgs[base_cfg[cfg]];
-        const int mt = 32 * c.wm * c.rm, ph = c.wn * c.rn * rpt, ck = conv_ck(d->ksize, c.rm * c.rn, false) * ckm;
+        DVC_REQUIRE(cfg >= 2 && cfg <= 4, "dvc_conv2d: the stream-K path has tile configurations 2, 3 and 4 (cfg 34..36)");
+        const ConvCfg& c = kConvCfgs[cfg];
+        const int mt = 32 * c.wm * c.rm, ph = c.wn * c.rn * rpt, ck = conv_ck(d->ksize, c.rm * c.rn, false);
         DVC_REQUIRE(!gen && !in_scale && !d->in_prelu && d->Cin % ck == 0 && d->Cout % mt == 0,
                     "dvc_conv2d: the stream-K path needs a plain stride-1 layer (no fused input transform, Cin %% %d == 0, "
                     "Cout %% %d == 0)", ck, mt);
         DVC_REQUIRE(workspace, "dvc_conv2d: the stream-K path needs a workspace");
+        DVC_REQUIRE((long)d->Cin * d->H * d->W * 4 < (1L << 31) && (long)d->Cin * d->ksize * d->ksize * d->Cout * 4 < (1L << 31),
+                    "dvc_conv2d: tensor too large for buffer-descriptor staging");
         ConvSkArgs sk;
         sk.k = a;
         sk.k.split = 1; sk.k.chunks_per_split = 0; sk.k.part = nullptr;
@@ -180,8 +175,6 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
         DVC_REQUIRE(tiles < (1L << 30), "dvc_conv2d: too many tiles");
         int per_cu = d->split_k > 0 ? d->split_k : 2;
         if (per_cu > 2) per_cu = 2;     // the kernel is register-allocated for 2 workgroups per CU
-        if (cfg == 23) per_cu = 1;      // (two 45 KB LDS buffers)
-
         long G = (long)per_cu * conv_num_cus();
         if (G > sk.U) G = sk.U;
         const size_t slot = (size_t)mt * (c.wn * c.rn * 32) * sizeof(float);

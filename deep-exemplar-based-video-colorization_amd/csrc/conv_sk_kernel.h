@@ -52,31 +52,16 @@ __device__ __forceinline__ long sk_logical_wg(long b, long G) {
     return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
 }
 
-// KA = independent accumulator chains per 32x32 tile (the chunk's channel pairs alternate between them).  A
-// single chain is a sequence of DEPENDENT MFMAs with the operand reads of the next one issued in between; on
-// gfx950 a dependent MFMA that does not directly follow its producer waits for the accumulator write-back
-// (MI355X_MICROARCH.md: +43 cycles for the first instruction slotted between two MFMAs on the same accumulator),
-// which one wave per SIMD cannot hide.  Two chains make every MFMA depend on the one before last.
-//
-// PIPE = operands double-buffered in REGISTERS: while the MFMAs of unit u run from one register set (36 + 36
-// values per lane for a 32x32 tile: everything one chunk needs), the ds_reads of unit u+1 fill the other set
-// and the LDS-DMA of unit u+2 refills the LDS buffer unit u was read from.  An MFMA never waits for LDS: a wave
-// alone on its SIMD measured 66 % matrix-pipe utilisation with the reads issued just ahead of their MFMAs
-// (~100 cycles of LDS latency against a 64-cycle MFMA), 80 % with a partner wave; this removes the dependence.
-//
-// BUF = staging by `buffer_load ... offen lds` through buffer descriptors instead of `global_load_lds` with per-lane
-// pointers: the per-chunk advance is the instruction's scalar offset (no VALU), and a lane whose tap reads padding (or
-// has no element) carries the offset 0x80000000, which the descriptor's range check turns into a zero written to LDS
-// (checked on the hardware: tools/hwprobe/buffer_lds_oob.hip) — no exec-mask branch per load, no clearing of padding
-// cells at tile switches.  The staging of a unit shrinks from ~130 instructions in ten basic blocks to ~25 straight-
-// line ones that the scheduler can place in the shadow of the MFMA chain.
-// DBGV (timing experiments only, results are wrong): bit 0 = no barrier in the steady state, bit 1 = no staging after
-// the first unit, bit 2 = MFMA operands from loop-invariant registers instead of LDS.
-// CKM = LDS chunk length in units of the engine's usual 8 (3x3) / 16 (1x1) input channels: 2 halves the number of
-// units (barriers, staging rounds, control flow) per MFMA at twice the LDS footprint.
-template <int WM, int WN, int RM, int RN, int TW, int KS, int DIL, int KA = 1, bool PIPE = false, bool BUF = false, int DBGV = 0,
-          int CKM = 1>
-__global__ __launch_bounds__(64 * WM * WN, (PIPE && RM * RN > 1) ? 1 : 2) void conv_sk_kernel(ConvSkArgs s) {
+// Staging is by `buffer_load ... offen lds` through buffer descriptors (not `global_load_lds` with per-lane pointers):
+// the per-chunk advance is the instruction's scalar offset (no VALU), and a lane whose tap reads padding (or has no
+// element) carries the offset 0x80000000, which the descriptor's range check turns into a zero written to LDS (checked
+// on the hardware: tools/hwprobe/buffer_lds_oob.hip) — no exec-mask branch per load, no zeroing of padding cells at tile
+// switches: the staging of a unit is ~35 straight-line instructions.
+// Measured and dropped (profiles/r02_conv_experiments.md): two accumulator chains per tile, operands double-buffered in
+// registers, double-length LDS chunks — none moved the time once the staging was this cheap; what is left above the MFMA
+// time is per-launch cost (ramp, first DMA, last flush, fixup), not the unit loop.
+template <int WM, int WN, int RM, int RN, int TW, int KS, int DIL>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_sk_kernel(ConvSkArgs s) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (the buffer-descriptor type and builtins exist in the device pass only; the host
                                       // pass needs nothing but the signature for its launch stub)
     const ConvKArgs& a = s.k;
@@ -85,7 +70,7 @@ __global__ __launch_bounds__(64 * WM * WN, (PIPE && RM * RN > 1) ? 1 : 2) void c
     constexpr int RPT = 32 / TW;
     constexpr int PH = WN * RN * RPT;
     constexpr int KK = KS * KS;
-    constexpr int CK = conv_ck(KS, RM * RN, false) * CKM;
+    constexpr int CK = conv_ck(KS, RM * RN, false);
     constexpr int ROW4 = MT / 4;
     constexpr int WPT = (CK * KK * ROW4 + NT - 1) / NT;
     constexpr int IH_T = PH + DIL * (KS - 1);
@@ -93,8 +78,8 @@ __global__ __launch_bounds__(64 * WM * WN, (PIPE && RM * RN > 1) ? 1 : 2) void c
     constexpr int IW_P = conv_pitch(TW, IW_T, 1, true);
     constexpr int plane = IH_T * IW_P;
     constexpr int EPT = (CK * plane + NT - 1) / NT;
-    // (BUF: every lane of every staging load writes its LDS slot, so the patch buffer covers all EPT*NT slots)
-    constexpr int C_XS = BUF ? EPT * NT : conv_xs_floats(CK, IH_T, IW_P);
+    // every lane of every staging load writes its LDS slot (padding lanes write zeros): the patch buffer covers all slots
+    constexpr int C_XS = EPT * NT;
     constexpr int C_WS = conv_ws_floats(CK, KK, MT);
     constexpr int NACC = RM * RN * 16;
     constexpr int OOB = (int)0x80000000;
@@ -133,9 +118,9 @@ __global__ __launch_bounds__(64 * WM * WN, (PIPE && RM * RN > 1) ? 1 : 2) void c
     for (int i = 0; i < WPT; ++i) {
         const int q = tid + i * NT;
         wrel[i] = q < nq ? (q / ROW4) * a.Cout + (q % ROW4) * 4 : -1;
-        if (BUF) wrel[i] = wrel[i] >= 0 ? wrel[i] * 4 : OOB;      // byte offset into the weight buffer
+        wrel[i] = wrel[i] >= 0 ? wrel[i] * 4 : OOB;      // byte offset into the weight buffer
     }
-    // buffer descriptors (BUF): the whole weight tensor; one image of the input (rebuilt when the staged image changes)
+    // buffer descriptors: the whole weight tensor; one image of the input (rebuilt when the staged image changes)
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cin * KK * a.Cout * 4, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.Cin * HWi * 4, 0x00020000);
     int rs_n = 0;
@@ -150,48 +135,25 @@ __global__ __launch_bounds__(64 * WM * WN, (PIPE && RM * RN > 1) ? 1 : 2) void c
                 const int o = stored_offset(a, vy0 + iy, vx0 + ix);
                 g = o >= 0 ? c * HWi + o : -1;
             }
-            gofs[t] = BUF ? (g >= 0 ? g * 4 : OOB) : g;
+            gofs[t] = g >= 0 ? g * 4 : OOB;
         }
-        if (BUF && t_.n != rs_n) {
+        if (t_.n != rs_n) {
             rs_n = t_.n;
             rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long)t_.n * a.x_bs), 0, a.Cin * HWi * 4, 0x00020000);
         }
     };
-    auto issue = [&](int c, const SkTile& t_, float* xs, float* ws) {
-        if constexpr (BUF) {
-            const int sx = c * CK * HWi * 4, sw = (c * CK * KK * a.Cout + t_.m0) * 4;
-#pragma unroll
-            for (int t = 0; t < EPT; ++t)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (CONV_AS3 void*)(xs + t * NT + wave * 64), 4, gofs[t], sx, 0, 0);
-#pragma unroll
-            for (int i = 0; i < WPT; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (CONV_AS3 void*)(ws + (i * NT + wave * 64) * 4), 16, wrel[i], sw, 0, 0);
-            return;
-        }
-        const float* xc = a.x + (long)t_.n * a.x_bs + (long)c * CK * HWi;
-        const float* wc = a.w + (long)c * CK * KK * a.Cout + t_.m0;
+    auto issue = [&](int c, float* xs, float* ws, int m0) {
+        const int sx = c * CK * HWi * 4, sw = (c * CK * KK * a.Cout + m0) * 4;
 #pragma unroll
         for (int t = 0; t < EPT; ++t)
-            if (gofs[t] >= 0)
-                __builtin_amdgcn_global_load_lds((const CONV_AS1 void*)(xc + (unsigned)gofs[t]),
-                                                 (CONV_AS3 void*)(xs + t * NT + wave * 64), 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (CONV_AS3 void*)(xs + t * NT + wave * 64), 4, gofs[t], sx, 0, 0);
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
-            if (wrel[i] >= 0)
-                __builtin_amdgcn_global_load_lds((const CONV_AS1 void*)(wc + (unsigned)wrel[i]),
-                                                 (CONV_AS3 void*)(ws + (i * NT + wave * 64) * 4), 16, 0, 0);
-    };
-    // cells of the staged tile that read padding zeros are never written by the DMA: clear them when a
-    // buffer is first used for a new tile (they may hold the previous tile's data)
-    auto clear_pad = [&](float* xs) {
-        if (BUF) return;   // out-of-range lanes write their zeros themselves
-#pragma unroll
-        for (int t = 0; t < EPT; ++t)
-            if (ecy[t] >= 0 && gofs[t] < 0) xs[t * NT + tid] = 0.f;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (CONV_AS3 void*)(ws + (i * NT + wave * 64) * 4), 16, wrel[i], sw, 0, 0);
     };
 
     // ---- accumulators: tot = running sum of the current tile segment, acc = one chunk's chain
-    f32x16 tot[RM][RN], acc[RM][RN][KA];
+    f32x16 tot[RM][RN], acc[RM][RN];
 #pragma unroll
     for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -241,139 +203,17 @@ __global__ __launch_bounds__(64 * WM * WN, (PIPE && RM * RN > 1) ? 1 : 2) void c
         }
     };
 
-    if constexpr (PIPE) {
-        static_assert(KA == 1 && RM * RN <= 2, "PIPE: one chain per tile, at most two tiles per wave (register budget)");
-        constexpr int NS = KK * (CK / 2);          // MFMA steps per unit and tile
-        // staging cursor: the next unit to DMA into LDS
-        long su = u;
-        int s_tile = (int)(u / NC), s_c = (int)(u - (long)s_tile * NC), fresh = 0;
-        SkTile s_geo = sk_decode(s, s_tile, MT, TW, PH);
-        plan(s_geo);
-        auto stage = [&](float* xs, float* ws) {   // issue the DMA of unit `su`, advance the cursor
-            if (fresh > 0) {
-                clear_pad(xs);
-                --fresh;
-            }
-            issue(s_c, s_geo, xs, ws);
-            ++su;
-            if (++s_c == NC) {
-                s_c = 0;
-                ++s_tile;
-                if (su < u1) {                      // (the plan of a tile nobody will stage is never computed)
-                    s_geo = sk_decode(s, s_tile, MT, TW, PH);
-                    plan(s_geo);
-                    fresh = 2;
-                }
-            }
-        };
-        auto load_regs = [&](const float* xs, const float* ws, float (&ra)[NS][RM], float (&rb)[NS][RN]) {
-            const float* wb = ws + woff;
-#pragma unroll
-            for (int tap = 0; tap < KK; ++tap) {
-                const int toff = (tap / KS) * DIL * IW_P + (tap % KS) * DIL;
-#pragma unroll
-                for (int kk = 0; kk < CK; kk += 2) {
-                    const int m = tap * (CK / 2) + kk / 2;
-#pragma unroll
-                    for (int i = 0; i < RM; ++i) ra[m][i] = wb[(kk * KK + tap) * MT + i * 32];
-#pragma unroll
-                    for (int j = 0; j < RN; ++j) rb[m][j] = xs[xoff[j] + kk * plane + toff];
-                }
-            }
-        };
-        int tile = (int)(u / NC), c = (int)(u - (long)tile * NC);
-        const int first_tile = tile;
-        int seg_c0 = c;
-        SkTile cur = s_geo;
-        float ra0[NS][RM], rb0[NS][RN], ra1[NS][RM], rb1[NS][RN];
-        for (int i = tid; i < C_XS / 4; i += NT) {
-            reinterpret_cast<float4*>(xsb0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            reinterpret_cast<float4*>(xsb1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-        stage(xsb0, wsb0);                          // unit u   -> buffer 0
-        __syncthreads();                            // landed
-        if (su < u1) stage(xsb1, wsb1);             // unit u+1 -> buffer 1
-        load_regs(xsb0, wsb0, ra0, rb0);            // unit u   -> register set 0
-        // One unit.  On entry: register set `cur` holds unit u (its ds_reads may still be in flight), the DMA of
-        // unit u+1 into the other LDS buffer may still be in flight, LDS buffer `mine` is being read by slower waves.
-        auto step = [&](float (&ra)[NS][RM], float (&rb)[NS][RN], float (&ra_n)[NS][RM], float (&rb_n)[NS][RN],
-                        float* xs_mine, float* ws_mine, const float* xs_other, const float* ws_other) {
-            const bool has_next = u + 1 < u1;
-            const bool tile_done = c + 1 == NC;
-            __syncthreads();   // my reads of unit u done; everyone's reads of `mine` done; unit u+1 landed in `other`
-            if (su < u1) stage(xs_mine, ws_mine);                     // unit u+2 -> the buffer unit u came from
-            // unit u+1 -> the other register set (unconditional: past the last unit it reads stale LDS bytes that
-            // nothing uses — keeps the reads in the MFMA chain's basic block so that they are interleaved with it)
-            load_regs(xs_other, ws_other, ra_n, rb_n);
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < RN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][0][r] = 0.f;
-#pragma unroll
-            for (int m = 0; m < NS; ++m)
-#pragma unroll
-                for (int i = 0; i < RM; ++i)
-#pragma unroll
-                    for (int j = 0; j < RN; ++j)
-                        acc[i][j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[m][i], rb[m][j], acc[i][j][0], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NS * RM * RN; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, RM + RN, 0); // the next unit's DS reads
-            }
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < RN; ++j) tot[i][j] += acc[i][j][0];
-            if (tile_done || !has_next) {
-                flush(cur, seg_c0 == 0 && tile_done, tile == first_tile ? 0 : 1);
-#pragma unroll
-                for (int i = 0; i < RM; ++i)
-#pragma unroll
-                    for (int j = 0; j < RN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
-                seg_c0 = 0;
-            }
-            if (tile_done) {
-                ++tile;
-                c = 0;
-                if (has_next) cur = sk_decode(s, tile, MT, TW, PH);
-            } else {
-                ++c;
-            }
-            ++u;
-        };
-        while (u < u1) {
-            step(ra0, rb0, ra1, rb1, xsb0, wsb0, xsb1, wsb1);
-            if (u < u1) step(ra1, rb1, ra0, rb0, xsb1, wsb1, xsb0, wsb0);
-        }
-        return;
-    }
-
     // ---- prologue: stage the first unit
     int tile = (int)(u / NC), c = (int)(u - (long)tile * NC);
     const int first_tile = tile;
     int seg_c0 = c;                      // first chunk of the current segment
     SkTile cur = sk_decode(s, tile, MT, TW, PH);
     SkTile stg = cur;                    // tile of the unit being staged
-    int stg_tile = tile, stg_c = c, fresh = 0;
+    int stg_tile = tile, stg_c = c;
     plan(cur);
-    if (!BUF) {   // (BUF: every slot is written by the staging loads, padding included)
-        for (int i = tid; i < C_XS / 4; i += NT) {
-            reinterpret_cast<float4*>(xsb0)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            reinterpret_cast<float4*>(xsb1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-    }
-    issue(c, cur, xsb0, wsb0);
-    __syncthreads();   // (drains the DMA: vmcnt(0) before the barrier)
+    issue(c, xsb0, wsb0, cur.m0);
+    __syncthreads();   // (drains the staging loads: vmcnt(0) before the barrier)
 
-    float dbg_a = 1.0f + lane, dbg_b = 0.5f * lane;
-    if (DBGV & 4) asm volatile("" : "+v"(dbg_a), "+v"(dbg_b));
     // One unit: stage unit u+1 into the other buffer, run unit u's MFMA chain, barrier, flush on a tile
     // boundary.  Everything that decides control flow is wave-uniform (derived from blockIdx).
     auto step = [&](const float* xs, const float* ws, float* xs_next, float* ws_next) {
@@ -385,15 +225,10 @@ __global__ __launch_bounds__(64 * WM * WN, (PIPE && RM * RN > 1) ? 1 : 2) void c
                 stg_c = 0;
                 stg = sk_decode(s, stg_tile, MT, TW, PH);
                 plan(stg);
-                fresh = 2;
             } else {
                 stg_c = c + 1;
             }
-            if (fresh > 0) {
-                clear_pad(xs_next);
-                --fresh;
-            }
-            if (!(DBGV & 2)) issue(stg_c, stg, xs_next, ws_next);
+            issue(stg_c, xs_next, ws_next, stg.m0);
         }
         const float* wb = ws + woff;
 #pragma unroll
@@ -401,25 +236,22 @@ __global__ __launch_bounds__(64 * WM * WN, (PIPE && RM * RN > 1) ? 1 : 2) void c
 #pragma unroll
             for (int j = 0; j < RN; ++j)
 #pragma unroll
-                for (int p = 0; p < KA; ++p)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][p][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             const int toff = (tap / KS) * DIL * IW_P + (tap % KS) * DIL;
 #pragma unroll
             for (int kk = 0; kk < CK; kk += 2) {
-                const int p = (tap * (CK / 2) + kk / 2) % KA;
                 float av[RM], bv[RN];
 #pragma unroll
-                for (int i = 0; i < RM; ++i) av[i] = (DBGV & 4) ? dbg_a : wb[(kk * KK + tap) * MT + i * 32];
+                for (int i = 0; i < RM; ++i) av[i] = wb[(kk * KK + tap) * MT + i * 32];
 #pragma unroll
-                for (int j = 0; j < RN; ++j) bv[j] = (DBGV & 4) ? dbg_b : xs[xoff[j] + kk * plane + toff];
+                for (int j = 0; j < RN; ++j) bv[j] = xs[xoff[j] + kk * plane + toff];
 #pragma unroll
                 for (int i = 0; i < RM; ++i)
 #pragma unroll
                     for (int j = 0; j < RN; ++j)
-                        acc[i][j][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j][p], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -430,11 +262,8 @@ __global__ __launch_bounds__(64 * WM * WN, (PIPE && RM * RN > 1) ? 1 : 2) void c
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j) {
-                if (KA == 2) tot[i][j] += acc[i][j][0] + acc[i][j][KA - 1];
-                else tot[i][j] += acc[i][j][0];
-            }
-        if (!(DBGV & 1)) __syncthreads();  // unit u+1 landed in LDS; everyone is done reading unit u
+            for (int j = 0; j < RN; ++j) tot[i][j] += acc[i][j];
+        __syncthreads();  // unit u+1 landed in LDS; everyone is done reading unit u
         if (tile_done || !has_next) {
             flush(cur, seg_c0 == 0 && tile_done, tile == first_tile ? 0 : 1);
 #pragma unroll
@@ -522,70 +351,30 @@ struct ConvSkLaunch {
     bool need_fixup;
 };
 
-template <int KS, int DIL, int WM, int WN, int RM, int RN, int TW, int KA = 1, bool PIPE = false, bool BUF = false, int DBGV = 0,
-          int CKM = 1>
+template <int KS, int DIL, int WM, int WN, int RM, int RN, int TW>
 static void conv_sk_launch_one(const ConvSkLaunch& L, hipStream_t st, const ConvSkArgs& s) {
     constexpr int NT = 64 * WM * WN;
-    hipLaunchKernelGGL((conv_sk_kernel<WM, WN, RM, RN, TW, KS, DIL, KA, PIPE, BUF, DBGV, CKM>), L.grid, dim3(NT), 0, st, s);
+    hipLaunchKernelGGL((conv_sk_kernel<WM, WN, RM, RN, TW, KS, DIL>), L.grid, dim3(NT), 0, st, s);
     if (L.need_fixup)
         hipLaunchKernelGGL((conv_sk_fixup_kernel<WM, WN, RM, RN, TW>), L.fix_grid, dim3(NT), 0, st, s, (long)L.grid.x);
 }
 
-template <int KS, int DIL, int WM, int WN, int RM, int RN, int KA = 1, bool PIPE = false, bool BUF = false>
+template <int KS, int DIL, int WM, int WN, int RM, int RN>
 static void conv_sk_launch_tw(int tw, const ConvSkLaunch& L, hipStream_t st, const ConvSkArgs& s) {
     switch (tw) {
-        case 32: conv_sk_launch_one<KS, DIL, WM, WN, RM, RN, 32, KA, PIPE, BUF>(L, st, s); break;
-        case 16: conv_sk_launch_one<KS, DIL, WM, WN, RM, RN, 16, KA, PIPE, BUF>(L, st, s); break;
-        default: conv_sk_launch_one<KS, DIL, WM, WN, RM, RN, 8, KA, PIPE, BUF>(L, st, s); break;
+        case 32: conv_sk_launch_one<KS, DIL, WM, WN, RM, RN, 32>(L, st, s); break;
+        case 16: conv_sk_launch_one<KS, DIL, WM, WN, RM, RN, 16>(L, st, s); break;
+        default: conv_sk_launch_one<KS, DIL, WM, WN, RM, RN, 8>(L, st, s); break;
     }
 }
 
+// tile configurations as in conv_kernel.h (kConvCfgs): 2 = 64 co x 4 N-tiles, 3 = 32 co x 4 N-tiles, 4 = 64 co x 2 N-tiles
 template <int KS, int DIL>
 static void conv_sk_launch_variant(int cfg, int tw, const ConvSkLaunch& L, hipStream_t st, const ConvSkArgs& s) {
     switch (cfg) {
-        case 0: conv_sk_launch_tw<KS, DIL, 1, 4, 2, 2>(tw, L, st, s); break;
-        case 1: conv_sk_launch_tw<KS, DIL, 1, 4, 1, 2>(tw, L, st, s); break;
         case 2: conv_sk_launch_tw<KS, DIL, 1, 4, 2, 1>(tw, L, st, s); break;
         case 3: conv_sk_launch_tw<KS, DIL, 1, 4, 1, 1>(tw, L, st, s); break;
-        case 4: conv_sk_launch_tw<KS, DIL, 2, 2, 1, 1>(tw, L, st, s); break;
-        case 5: conv_sk_launch_tw<KS, DIL, 2, 2, 1, 1, 2>(tw, L, st, s); break;   // cfg 4 with two accumulator chains
-        case 6: conv_sk_launch_tw<KS, DIL, 1, 4, 1, 1, 2>(tw, L, st, s); break;   // cfg 3 with two accumulator chains
-        case 7: conv_sk_launch_tw<KS, DIL, 2, 2, 1, 1, 1, true>(tw, L, st, s); break;   // cfg 4, operands pipelined through registers
-        case 8: conv_sk_launch_tw<KS, DIL, 1, 4, 1, 1, 1, true>(tw, L, st, s); break;   // cfg 3, pipelined
-        case 9: conv_sk_launch_tw<KS, DIL, 2, 2, 1, 1, 1, false, true>(tw, L, st, s); break;   // cfg 4, buffer-descriptor staging
-        case 10: conv_sk_launch_tw<KS, DIL, 2, 2, 1, 1, 1, true, true>(tw, L, st, s); break;   // cfg 4, pipelined + buffer staging
-        case 11: conv_sk_launch_tw<KS, DIL, 1, 4, 1, 1, 1, false, true>(tw, L, st, s); break;  // cfg 3, buffer staging
-        case 12: conv_sk_launch_tw<KS, DIL, 1, 4, 2, 1, 1, false, true>(tw, L, st, s); break;  // cfg 2, buffer staging
-        case 13: conv_sk_launch_tw<KS, DIL, 1, 4, 2, 2, 1, false, true>(tw, L, st, s); break;  // cfg 0, buffer staging
-        case 22:   // cfg 3 (32 co x 4 N-tiles), buffer staging, double-length chunks
-            switch (tw) {
-                case 32: conv_sk_launch_one<KS, DIL, 1, 4, 1, 1, 32, 1, false, true, 0, 2>(L, st, s); break;
-                case 16: conv_sk_launch_one<KS, DIL, 1, 4, 1, 1, 16, 1, false, true, 0, 2>(L, st, s); break;
-                default: conv_sk_launch_one<KS, DIL, 1, 4, 1, 1, 8, 1, false, true, 0, 2>(L, st, s); break;
-            }
-            break;
-        case 23:   // cfg 4 (64 co x 2 N-tiles), buffer staging, double-length chunks (one workgroup per CU: LDS)
-            switch (tw) {
-                case 32: conv_sk_launch_one<KS, DIL, 2, 2, 1, 1, 32, 1, false, true, 0, 2>(L, st, s); break;
-                case 16: conv_sk_launch_one<KS, DIL, 2, 2, 1, 1, 16, 1, false, true, 0, 2>(L, st, s); break;
-                default: conv_sk_launch_one<KS, DIL, 2, 2, 1, 1, 8, 1, false, true, 0, 2>(L, st, s); break;
-            }
-            break;
-        default:
-            // timing experiments (3x3 dilation-1 only): cfg 9 with parts of the unit loop removed, 14 + DBGV
-            if constexpr (KS == 3 && DIL == 1) {
-                if (tw == 32) {
-                    switch (cfg - 14) {
-                        case 1: conv_sk_launch_one<KS, DIL, 2, 2, 1, 1, 32, 1, false, true, 1>(L, st, s); break;
-                        case 2: conv_sk_launch_one<KS, DIL, 2, 2, 1, 1, 32, 1, false, true, 2>(L, st, s); break;
-                        case 3: conv_sk_launch_one<KS, DIL, 2, 2, 1, 1, 32, 1, false, true, 3>(L, st, s); break;
-                        case 4: conv_sk_launch_one<KS, DIL, 2, 2, 1, 1, 32, 1, false, true, 4>(L, st, s); break;
-                        case 6: conv_sk_launch_one<KS, DIL, 2, 2, 1, 1, 32, 1, false, true, 6>(L, st, s); break;
-                        default: conv_sk_launch_one<KS, DIL, 2, 2, 1, 1, 32, 1, false, true, 7>(L, st, s); break;
-                    }
-                }
-            }
-            break;
+        default: conv_sk_launch_tw<KS, DIL, 2, 2, 1, 1>(tw, L, st, s); break;
     }
 }
 

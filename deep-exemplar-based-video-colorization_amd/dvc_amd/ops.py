@@ -156,7 +156,7 @@ if _autotune:
 
 # split-K candidates of the autotuner (DVC_TUNE_SPLITS=1 disables split-K: experiments only)
 _TUNE_SPLITS = tuple(int(v) for v in _os.environ.get("DVC_TUNE_SPLITS", "1,2,3,4,6,8").split(","))
-_TUNE_STREAMK = tuple((int(a), int(b)) for a, b in (v.split(":") for v in _os.environ.get("DVC_TUNE_STREAMK", "41:2,41:1").split(",") if v))
+_TUNE_STREAMK = tuple((int(a), int(b)) for a, b in (v.split(":") for v in _os.environ.get("DVC_TUNE_STREAMK", "36:2,36:1").split(",") if v))
 
 
 def _tune_conv(lib, d, tensors):
@@ -192,8 +192,8 @@ def _tune_conv(lib, d, tensors):
             t = time_it()
             if t < best_t:
                 best, best_t = (cfg, sk), t
-    # stream-K decomposition (plain stride-1 layers only; the call fails cleanly otherwise): 64x64 tiles with
-    # buffer-descriptor staging, 1 or 2 workgroups per CU
+    # stream-K decomposition (cfg 32 + tile configuration; plain stride-1 layers only, the call fails cleanly otherwise):
+    # 64x64 tiles, 1 or 2 workgroups per CU
     for cfg, per_cu in _TUNE_STREAMK:
         d.cfg, d.split_k = cfg, per_cu
         if launch() != 0:

@@ -57,6 +57,9 @@ const char* dvc_last_error(void);
  * Layers too small to fill the 1024 SIMDs are split over input-channel chunks (split-K): partial sums
  * go to `workspace` ([S][N][Cout][OH][OW] floats) and a second tiny kernel adds them in a fixed order and
  * applies bias / residual / activation.  Without a workspace split-K is off.
+ * Alternatively (cfg 32 + k) the layer is decomposed stream-K style: the (tile, channel-chunk) units are dealt in
+ * equal contiguous ranges to a grid that exactly fills the chip; tiles that a range boundary splits go through
+ * per-workgroup slots in `workspace` and a fixed-order fixup kernel (csrc/conv_sk_kernel.h).
  */
 enum { DVC_ACT_NONE = 0, DVC_ACT_RELU = 1, DVC_ACT_PRELU = 2, DVC_ACT_LEAKY = 3, DVC_ACT_TANH128 = 4 };
 enum { DVC_PAD_ZERO = 0, DVC_PAD_REFLECT = 1 };
@@ -76,8 +79,10 @@ typedef struct DvcConvDesc {
     int32_t in_prelu;           /* apply PReLU (slope *in_slope_ptr) to the affine-transformed input */
     int32_t cfg;                /* tile configuration 0..4; -1 = choose automatically; 16 + k = configuration k
                                    with register staging forced (layers without a fused input transform
-                                   otherwise stage through LDS-DMA) */
-    int32_t split_k;            /* 0 = automatic, 1 = off, 2..8 = forced (needs a workspace) */
+                                   otherwise stage through LDS-DMA); 32 + k (k = 2, 3, 4) = stream-K decomposition
+                                   of a plain stride-1 layer with tile configuration k (needs a workspace) */
+    int32_t split_k;            /* 0 = automatic, 1 = off, 2..8 = forced (needs a workspace); with cfg >= 32:
+                                   workgroups per CU (0 -> 2) */
     int64_t x_batch_stride;     /* elements; 0 => Cin*H*W */
     int64_t y_batch_stride;     /* elements; 0 => Cout*OH*OW  (lets y be a channel slice) */
     int64_t res_batch_stride;   /* elements; 0 => Cout*OH*OW */

@@ -506,3 +506,26 @@ def test_clip_pipelined_equals_sequential():
     rest = cc.clip(frames[3:], last=cc.last_lab, lookahead=2)
     for a, b in zip(first + rest, ref):
         assert torch.equal(a, b)
+
+
+def test_luminance_noise_path(nets):
+    """frame_colorization(luminance_noise=s) (models/FrameColor.py:55-57) adds s * randn to the L channel that feeds BOTH
+    the VGG front end and ColorVidNet's first input channel: equal, bit for bit, to a call with the same noise already
+    added to IA_lab (same device generator state), and different from the noise-free call."""
+    from dvc_amd import ops, synth
+    from dvc_amd.frame import VGG_OUT, frame_colorization
+    vgg, warp, col = nets
+    H, W, T, s = 48, 80, 0.01, 2.5
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).cuda()
+    fr = synth.synth_lab(synth.FRAME_SEED0, H, W).cuda()
+    last = synth.synth_lab(synth.FRAME_SEED0 - 1, H, W).cuda()
+    fB = vgg(ops.lab2rgb(IB, l_offset=50.0), VGG_OUT)
+    torch.manual_seed(1234)
+    ab_n, nl_n, _ = frame_colorization(fr, IB, last, fB, vgg, warp, col, joint_training=False, luminance_noise=s, temperature=T)
+    torch.manual_seed(1234)
+    noise = torch.randn_like(fr[:, 0:1]) * s
+    fr2 = torch.cat((fr[:, 0:1] + noise, fr[:, 1:3]), dim=1).contiguous()
+    ab_p, nl_p, _ = frame_colorization(fr2, IB, last, fB, vgg, warp, col, joint_training=False, temperature=T)
+    assert torch.equal(ab_n, ab_p) and torch.equal(nl_n, nl_p)
+    ab_0, _, _ = frame_colorization(fr, IB, last, fB, vgg, warp, col, joint_training=False, temperature=T)
+    assert (ab_0 - ab_n).abs().max().item() > 1e-3

@@ -82,7 +82,7 @@ for k, (r, count) in uniq.items():
                 pass
     err = {}
     if plain:
-        for cfg in (36, 39, 41, 42, 43, 44, 45):
+        for cfg in (34, 35, 36):
             for per_cu in (1, 2):
                 try:
                     times[f"sk{cfg - 32}/w{per_cu}"] = timeit(lambda: run(cfg, per_cu))

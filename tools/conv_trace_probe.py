@@ -15,7 +15,7 @@ for (ci, co, H, W) in ((256, 256, 54, 96), (512, 512, 27, 48)):
     wt = torch.randn(ci, 9, co, device=dev) * 0.05
     b = torch.randn(co, device=dev)
     out = torch.empty(1, co, H, W, device=dev)
-    for cfg, sk in ((41, 2), (41, 1), (4, 3), (4, 1), (53, 2), (53, 1)):
+    for cfg, sk in ((36, 2), (36, 1), (4, 3), (4, 1)):
         for _ in range(30):
             ops.conv2d(x, wt, b, pad=1, act=1, cfg=cfg, split_k=sk, out=out)
         torch.cuda.synchronize()
