@@ -151,6 +151,17 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     if (gen) DVC_REQUIRE(d->ksize == 3, "dvc_conv2d: stride-2 / dilated variant supports ksize 3 only");
     int cfg = d->cfg;
     bool allow_dma = true;
+    // Automatic choice, 3x3 layers with >= 256 input channels and no fused input transform (the 54x96 / 27x48 trunks of
+    // WarpNet and ColorVidNet and the two widest decoder layers): the stream-K decomposition with 64x64 tiles and two
+    // workgroups per CU wins on every one of them (profiles/r02_conv_layer_sweep.json: 62-64 us against 67-75 us).
+    int sk_per_cu = d->split_k;
+    if (cfg < 0 && d->split_k == 0 && workspace && !gen && !in_scale && !d->in_prelu && d->ksize == 3 && d->Cin >= 256 &&
+        d->Cin % 8 == 0 && d->Cout % 64 == 0 &&
+        (size_t)2 * conv_num_cus() * 2 * 64 * 64 * sizeof(float) <= workspace_bytes &&
+        (long)d->Cin * d->H * d->W * 4 < (1L << 31) && (long)d->Cin * 9 * d->Cout * 4 < (1L << 31)) {
+        cfg = 36;
+        sk_per_cu = 2;
+    }
     if (cfg >= 32) {
         // 32 + tile configuration (2, 3 or 4): stream-K decomposition (conv_sk_kernel.h); split_k = workgroups per CU (0 -> 2)
         cfg -= 32;
@@ -173,7 +184,7 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
         const long tiles = (long)d->N * sk.co_blocks * sk.px_tiles;
         sk.U = tiles * sk.NC;
         DVC_REQUIRE(tiles < (1L << 30), "dvc_conv2d: too many tiles");
-        int per_cu = d->split_k > 0 ? d->split_k : 2;
+        int per_cu = sk_per_cu > 0 ? sk_per_cu : 2;
         if (per_cu > 2) per_cu = 2;     // the kernel is register-allocated for 2 workgroups per CU
         long G = (long)per_cu * conv_num_cus();
         if (G > sk.U) G = sk.U;

@@ -21,7 +21,9 @@ for _ in range(5):
 # (Cin, Cout, H, W, dil, cfg, split_k): the configurations the autotuner picks for these layers
 shapes = [(512, 512, 27, 48, 1, 4, 3), (256, 256, 54, 96, 1, 4, 1), (128, 128, 216, 384, 1, 4, 1),
           (128, 128, 108, 192, 1, 4, 1), (512, 512, 27, 48, 2, 4, 3), (64, 64, 216, 384, 1, 3, 1),
-          (256, 256, 54, 96, 1, 0, 2)]
+          (256, 256, 54, 96, 1, 0, 2),
+          # stream-K (cfg 32 + tile configuration, split_k = workgroups per CU)
+          (256, 256, 54, 96, 1, 36, 2), (512, 512, 27, 48, 1, 36, 2), (128, 128, 216, 384, 1, 36, 2)]
 for (ci, co, H, W, dil, cfg, sk) in shapes:
     x = torch.randn(1, ci, H, W, device=dev)
     wt = torch.randn(ci, 9, co, device=dev) * 0.05

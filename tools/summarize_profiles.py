@@ -47,7 +47,7 @@ lines = ["# PMC summary (" + tag + ")", "",
          "| kernel | us | clock GHz | waves | MFMA util | per-wave kcycles: alive / own-MFMA / active / wait-inst / wait-any | VALU/wave | LDS bank-conflict cyc | HBM read MB (2xFETCH) | HBM write MB |",
          "|---|---|---|---|---|---|---|---|---|---|"]
 for k, v in agg.items():
-    if "conv_mfma" not in k and "corr_fwd" not in k:
+    if "conv_mfma" not in k and "corr_fwd" not in k and "conv_sk_kernel" not in k:
         continue
     c = {n: sum(x) / len(x) for n, x in v.items()}
     if "GRBM_GUI_ACTIVE" not in c:
@@ -56,12 +56,25 @@ for k, v in agg.items():
     cyc = c["GRBM_GUI_ACTIVE"] / 8
     w = c["SQ_WAVES"]
     lines.append("| `%s` | %.0f | %.2f | %d | %.1f%% | %.0f / %.0f / %.0f / %.0f / %.0f | %.0f | %.0f | %.1f | %.1f |" % (
-        k.replace("void ", "").replace("(ConvKArgs)", "").replace("(CorrArgs)", ""), us, cyc / us / 1e3, w,
+        k.replace("void ", "").replace("(ConvKArgs)", "").replace("(CorrArgs)", "").replace("(ConvSkArgs)", ""), us, cyc / us / 1e3, w,
         100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), c["SQ_WAVE_CYCLES"] * 4 / w / 1e3,
         c["SQ_VALU_MFMA_BUSY_CYCLES"] / w / 1e3, c["SQ_ACTIVE_INST_ANY"] * 4 / w / 1e3,
         c["SQ_WAIT_INST_ANY"] * 4 / w / 1e3, c.get("SQ_WAIT_ANY", 0) * 4 / w / 1e3, c.get("SQ_INSTS_VALU", 0) / w,
         c.get("SQ_LDS_BANK_CONFLICT", 0), 2 * c.get("FETCH_SIZE", 0) / 1024, c.get("WRITE_SIZE", 0) / 1024))
 if len(lines) > 9:
     open(os.path.join(P, f"{tag}_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
+# the correlation kernel's HBM traffic per launch, the number bench.py's roofline.traffic cites (file + hash)
+for k, v in agg.items():
+    if "corr_fwd_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        rd = 2.0 * 1024 * sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
+        wr = 1024.0 * sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+        rec = {"kernel": k.replace("void ", "").replace("(CorrArgs)", ""), "P": 5184, "bytes_per_launch": round(rd + wr),
+               "read_bytes": round(rd), "write_bytes": round(wr), "compulsory_bytes": 10760000,
+               "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/prof_kernels.py; "
+                         "read = 2 x FETCH_SIZE (gfx950: 64 B tallied per 128-B request, MI355X_MICROARCH.md), averaged over the "
+                         "launches of the kernel",
+               "measured_on": f"{tag} (profiles/{tag}_pmc_summary.md)"}
+        json.dump(rec, open(os.path.join(P, "corr_traffic.json"), "w"))
+        print("corr traffic:", rec["bytes_per_launch"], "bytes per launch")
 print("\n".join(lines[-8:]))
 print("profiles/:", sorted(os.listdir(P)))

@@ -81,8 +81,28 @@ for k, (r, count) in uniq.items():
         e1.record()
         torch.cuda.synchronize()
         times[f"sk{sk}"] = e0.elapsed_time(e1) / 8 * 1e3
+    # stream-K decomposition: cfg 32 + tile configuration, split_k = workgroups per CU (plain stride-1 layers only)
+    if plain and r["stride"] == 1:
+        for cfg in (34, 35, 36):
+            for per_cu in (1, 2):
+                def run():
+                    ops.conv2d(x, w, b, ksize=r["ksize"], stride=r["stride"], dil=r["dil"], pad=r["pad"],
+                               pad_mode=r["pad_mode"], in_up=r["in_up"], in_sub=r["in_sub"], act=r["act"], act_slope=0.2,
+                               residual=res, out=out, cfg=cfg, split_k=per_cu)
+                try:
+                    for _ in range(2):
+                        run()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(8):
+                        run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    times[f"streamk{cfg - 32}/w{per_cu}"] = e0.elapsed_time(e1) / 8 * 1e3
+                except RuntimeError:
+                    pass
     flops = 2.0 * r["N"] * r["Cout"] * OH * OW * r["Cin"] * r["ksize"] ** 2
-    valid = {c: t for c, t in times.items() if t is not None and isinstance(c, int) and c >= 0}
+    valid = {c: t for c, t in times.items() if t is not None and c != -1}
     best = min(valid, key=valid.get)
     results.append(dict(shape=r, count=count, OH=OH, OW=OW, gflop=flops / 1e9, us=times, best=best,
                         tflops_auto=flops / times[-1] / 1e6, tflops_best=flops / valid[best] / 1e6))
@@ -96,6 +116,6 @@ print(f"conv time per frame: auto {tot_auto / 1e3:.2f} ms, best-per-layer {tot_b
 for d in results[:45]:
     s = d["shape"]
     print(f'{d["count"]}x {"plain" if not s["affine"] and not s["in_prelu"] else "xform"} Cin={s["Cin"]:3d} Cout={s["Cout"]:3d} {s["H"]}x{s["W"]}->{d["OH"]}x{d["OW"]} k{s["ksize"]} s{s["stride"]} d{s["dil"]} '
-          f'up{s["in_up"]} sub{s["in_sub"]}: auto {d["us"][-1]:.0f}us ({d["tflops_auto"]:.1f} TF) best cfg{d["best"]} '
+          f'up{s["in_up"]} sub{s["in_sub"]}: auto {d["us"][-1]:.0f}us ({d["tflops_auto"]:.1f} TF) best {d["best"]} '
           f'{d["us"][d["best"]]:.0f}us ({d["tflops_best"]:.1f} TF) all=' + " ".join(
               f'{c}:{(t if t else 0):.0f}' for c, t in d["us"].items() if c != -1))
