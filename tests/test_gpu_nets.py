@@ -323,28 +323,44 @@ def test_clip_recurrence_cached_equals_uncached_and_deterministic(nets):
         assert torch.equal(x, y) and torch.equal(x, z)
 
 
-def test_batch_of_two_frames_matches_single_frame_runs(nets):
-    """The API is batched (train.py:402 calls it with B=16): a B=2 call must equal two B=1 calls, including
-    the exemplar batch.  The warped colours are bit-identical; the conv engine may pick a different tile /
-    split-K configuration for a different batch size (different fp32 summation order), so `ab` is compared
-    at fp32-noise level (the network amplifies 1e-7 input differences to ~1e-4)."""
+def test_batch_of_two_frames_matches_single_frame_runs(nets, weights):
+    """The API is batched (train.py:402 calls it with B=16): a B=2 call must equal two B=1 calls, including the exemplar
+    batch.  The conv engine may decompose a layer differently for a different batch size (tile configuration, split-K or
+    stream-K ranges: another fp32 summation order), so the comparison is made where fp32 noise is not amplified: the
+    well-conditioned ColorVidNet weights (synth, contractive=True) and, for the literal bound, the hard arg-max of test.py
+    (T = 1e-10: identical warped colours); at the soft temperature the warped colours agree at the level the affinities'
+    fp32 noise allows (d y / d f = |Lab| / T)."""
+    import contextlib
+    import io
     from dvc_amd import ops, synth
     from dvc_amd.frame import VGG_OUT, frame_colorization
-    vgg, warp, col = nets
-    H, W, T = 48, 80, 0.01
+    from models.ColorVidNet import ColorVidNet
+    vgg, warp, _ = nets
+    with contextlib.redirect_stdout(io.StringIO()):
+        col = ColorVidNet(7)
+    col.load_state_dict(synth.colorvidnet_state_dict(0, contractive=True))
+    col.eval().cuda()
+    H, W = 48, 80
     IB = torch.cat([synth.synth_lab(2, H, W), synth.synth_lab(3, H, W)]).cuda()
     IA = torch.cat([synth.synth_lab(1000, H, W), synth.synth_lab(1001, H, W)]).cuda()
     last = torch.cat([synth.synth_lab(7, H, W), synth.synth_lab(8, H, W)]).cuda()
     fB = vgg(ops.lab2rgb(IB, l_offset=50.0), VGG_OUT)
-    ab2, nl2, fA2 = frame_colorization(IA, IB, last, fB, vgg, warp, col, joint_training=False, temperature=T)
-    assert ab2.shape == (2, 2, H, W) and nl2.shape == (2, 3, H, W) and fA2[0].shape[0] == 2
-    for i in range(2):
-        fBi = vgg(ops.lab2rgb(IB[i:i + 1].contiguous(), l_offset=50.0), VGG_OUT)
-        ab1, nl1, _ = frame_colorization(IA[i:i + 1].contiguous(), IB[i:i + 1].contiguous(), last[i:i + 1].contiguous(),
-                                         fBi, vgg, warp, col, joint_training=False, temperature=T)
-        assert (nl2[i:i + 1] - nl1).abs().max().item() < 2e-2, i      # soft temperature: see corr tests
-        d = (ab2[i:i + 1] - ab1).abs()
-        assert d.mean().item() < 2e-3 and d.max().item() < 5e-2, (i, d.mean().item(), d.max().item())
+    for T in (1e-10, 0.01):
+        ab2, nl2, fA2 = frame_colorization(IA, IB, last, fB, vgg, warp, col, joint_training=False, temperature=T)
+        assert ab2.shape == (2, 2, H, W) and nl2.shape == (2, 3, H, W) and fA2[0].shape[0] == 2
+        for i in range(2):
+            fBi = vgg(ops.lab2rgb(IB[i:i + 1].contiguous(), l_offset=50.0), VGG_OUT)
+            ab1, nl1, _ = frame_colorization(IA[i:i + 1].contiguous(), IB[i:i + 1].contiguous(), last[i:i + 1].contiguous(),
+                                             fBi, vgg, warp, col, joint_training=False, temperature=T)
+            dn = (nl2[i:i + 1] - nl1).abs().max().item()
+            d = (ab2[i:i + 1] - ab1).abs()
+            report(f"batch-of-2 vs single T={T} image {i}: warped max diff {dn:.2e}, ab max diff {d.max().item():.2e} mean {d.mean().item():.2e}")
+            if T < 1e-6:
+                assert dn == 0.0, (i, dn)                    # same exemplar position on every row
+                assert d.max().item() < 1e-3, (i, d.max().item())
+            else:
+                assert dn < 2e-2, (i, dn)
+                assert d.mean().item() < 2e-3, (i, d.mean().item())
 
 
 def test_drop_in_signature_and_loud_cpu_failure(nets):
