@@ -115,7 +115,11 @@ def test_gpu_tail_matches_oracle(hw, report=print):
     ref = np.stack([T.fgs_filter(guide.cpu().numpy(), src[k].numpy()) for k in range(2)])
     err = np.abs(got - ref).max()
     print(f"fgs {H}x{W}: max abs err vs oracle {err:.2e} (values ~{np.abs(ref).max():.1f})")
-    assert err < 2e-3
+    import os
+    rp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "test_report.txt")
+    os.makedirs(os.path.dirname(rp), exist_ok=True)
+    open(rp, "a").write(f"fgs {H}x{W}: kernel vs oracle max abs err {err:.2e} (values ~{np.abs(ref).max():.1f})\n")
+    assert err < 3e-4          # two float32 evaluations of the same recurrences on values of ~100 (measured ~6e-5)
     rgb = tail.lab_to_rgb8(L[0, 0].cuda(), torch.from_numpy(ref).cuda()).cpu().numpy()
     ref8 = T.lab_to_rgb8(L[0, 0].numpy(), ref)
     d = np.abs(rgb.astype(np.int32) - ref8.astype(np.int32))
@@ -132,7 +136,7 @@ def test_gpu_frame_tail_end_to_end():
     ab = torch.randn(1, 2, H, W, generator=g) * 25
     rgb, cur = tail.frame_tail(lab_large.cuda(), ab.cuda())
     rgb_o, cur_o = T.frame_tail(L.numpy(), ab.numpy())
-    assert np.abs(cur.cpu().numpy() - cur_o).max() < 2e-3
+    assert np.abs(cur.cpu().numpy() - cur_o).max() < 3e-4
     d = np.abs(rgb.cpu().numpy().astype(np.int32) - rgb_o.astype(np.int32))
     assert d.max() <= 1
     rgb2, cur2 = tail.frame_tail(lab_large.cuda(), ab.cuda(), wls_filter_on=False)
