@@ -26,7 +26,7 @@ struct ConvSkArgs {
     int co_blocks;   // Cout / MT
     int NC;          // chunks (units) per tile = Cin / CK
     long U;          // units = N * co_blocks * px_tiles * NC
-    float* part;     // [G][2][RM*RN*16][NT] raw accumulator images
+    float* part;     // [G][2][RM*RN*4][NT] float4: raw accumulator images (thread-major 16-byte pieces)
 };
 
 __host__ __device__ __forceinline__ long sk_unit_start(long w, long U, long G) { return w * U / G; }
@@ -50,6 +50,60 @@ __device__ __forceinline__ SkTile sk_decode(const ConvSkArgs& s, int tile, int M
 __device__ __forceinline__ long sk_logical_wg(long b, long G) {
     const long xq = G / 8, xr = G % 8, xcd = b % 8, xi = b / 8;
     return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+}
+
+// Sum of the slots of one split tile in ascending-K (workgroup) order + bias / skip / activation -> y.  Executed by all
+// NT threads of one workgroup for the accumulator registers [k0, k0 + KPB) of every thread (thread <-> element map of
+// the main kernel).  slot 0 = the segment at the START of a workgroup's range, slot 1 = the one at its end: only the
+// first contributor can hold the tile at the end of its range; every later contributor's range starts inside the tile.
+template <int WM, int WN, int RM, int RN, int TW, int K0, int KPB>
+__device__ __forceinline__ void sk_fix_tile(const ConvSkArgs& s, long G, int tile, int tid) {
+    const ConvKArgs& a = s.k;
+    constexpr int NT = 64 * WM * WN;
+    constexpr int MT = 32 * WM * RM;
+    constexpr int RPT = 32 / TW;
+    constexpr int PH = WN * RN * RPT;
+    constexpr int NQ = RM * RN * 4;          // float4 pieces per thread and slot
+    static_assert(K0 % 4 == 0 && KPB % 4 == 0, "whole float4 pieces");
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const long uf = (long)tile * s.NC, ul = uf + s.NC - 1;
+    const long wf = sk_unit_owner(uf, s.U, G), wl = sk_unit_owner(ul, s.U, G);
+    const int slot_f = (sk_unit_start(wf, s.U, G) / s.NC == tile) ? 0 : 1;
+    float4 v[KPB / 4];
+    {
+        const float4* pp = reinterpret_cast<const float4*>(s.part) + ((wf * 2 + slot_f) * NQ + K0 / 4) * NT + tid;
+#pragma unroll
+        for (int q = 0; q < KPB / 4; ++q) v[q] = pp[(long)q * NT];
+    }
+    for (long w = wf + 1; w <= wl; ++w) {
+        const float4* pp = reinterpret_cast<const float4*>(s.part) + ((w * 2) * NQ + K0 / 4) * NT + tid;
+#pragma unroll
+        for (int q = 0; q < KPB / 4; ++q) {
+            const float4 t = pp[(long)q * NT];
+            v[q].x += t.x; v[q].y += t.y; v[q].z += t.z; v[q].w += t.w;
+        }
+    }
+    const SkTile t_ = sk_decode(s, tile, MT, TW, PH);
+    const float slope = a.act_slope_ptr ? *a.act_slope_ptr : a.act_slope;
+    const long OHW = (long)a.OH * a.OW;
+    float* yn = a.y + (long)t_.n * a.y_bs;
+    const float* rn_ = a.res ? a.res + (long)t_.n * a.res_bs : nullptr;
+    const int pr = l31 / TW, pc = l31 % TW;
+#pragma unroll
+    for (int k = 0; k < KPB; ++k) {
+        const int kk = K0 + k, ij = kk / 16, r = kk % 16, i = ij / RN, j = ij % RN;
+        const int oy = t_.oy0 + (wn * RN + j) * RPT + pr, ox = t_.ox0 + pc;
+        if (oy >= a.OH || ox >= a.OW) continue;
+        const long pix = (long)oy * a.OW + ox;
+        const int co = t_.m0 + (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float4 q4 = v[k / 4];
+        float o = (k % 4 == 0) ? q4.x : (k % 4 == 1) ? q4.y : (k % 4 == 2) ? q4.z : q4.w;
+        if (a.bias) o += a.bias[co];
+        if (rn_) o += rn_[(long)co * OHW + pix];
+        yn[(long)co * OHW + pix] = apply_act(o, a.act, slope);
+    }
 }
 
 // Staging is by `buffer_load ... offen lds` through buffer descriptors (not `global_load_lds` with per-lane pointers):
@@ -173,13 +227,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sk_kernel(ConvSkArgs s) 
     // flush the finished segment of tile `t_`: y (full tile) or this workgroup's slot (partial)
     auto flush = [&](const SkTile& t_, bool full, int slot) {
         if (!full) {
-            float* pp = s.part + ((long)(wlog * 2 + slot) * NACC) * NT + tid;
+            float4* pp = reinterpret_cast<float4*>(s.part) + ((long)(wlog * 2 + slot) * (NACC / 4)) * NT + tid;
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
                 for (int j = 0; j < RN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) pp[(long)((i * RN + j) * 16 + r) * NT] = tot[i][j][r];
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        pp[(long)((i * RN + j) * 4 + r4) * NT] = make_float4(tot[i][j][r4 * 4 + 0], tot[i][j][r4 * 4 + 1],
+                                                                              tot[i][j][r4 * 4 + 2], tot[i][j][r4 * 4 + 3]);
             return;
         }
         float* yn = a.y + (long)t_.n * a.y_bs;
@@ -290,58 +346,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sk_kernel(ConvSkArgs s) 
 
 // Second stage: every tile that was split over several workgroups = sum of their slots in ascending-K order
 // (workgroup order) + bias / skip / activation.  One workgroup per tile, same thread <-> element map as above.
-// Each tile is handled by SK_FIX_SPLIT workgroups (blockIdx.y), a quarter of the accumulator registers each: four times
-// the loads in flight, chains a quarter as long (this kernel is pure latency).
+// Second stage: one launch over the tiles; each split tile is handled by SK_FIX_SPLIT workgroups (blockIdx.y), a quarter of
+// the accumulator registers each (this kernel is pure latency).  An in-kernel form of this step — the last contributor of a
+// tile to finish adds the slots up, found through per-tile arrival counters, write-through slot stores and one agent-scope
+// acquire (no spinning) — was built, verified bit-identical under load, and measured SLOWER on the 6-GFLOP layers (69.0 vs
+// 63.8 us at 256->256 54x96, 66.2 vs 60.7 at 512->512 27x48; profiles/r02_conv_inkernel_fixup_probe.txt): the drain +
+// atomic + acquire + dependent loads at the end of every workgroup cost more than this 5 us launch.  Removed.
 #define SK_FIX_SPLIT 4
 template <int WM, int WN, int RM, int RN, int TW>
 __global__ __launch_bounds__(64 * WM * WN) void conv_sk_fixup_kernel(ConvSkArgs s, long G) {
-    const ConvKArgs& a = s.k;
-    constexpr int NT = 64 * WM * WN;
-    constexpr int MT = 32 * WM * RM;
-    constexpr int RPT = 32 / TW;
-    constexpr int PH = WN * RN * RPT;
     constexpr int NACC = RM * RN * 16;
-    constexpr int KPB = NACC / SK_FIX_SPLIT;     // accumulator registers per workgroup (a multiple of 4)
+    constexpr int KPB = NACC / SK_FIX_SPLIT;
     const int tile = blockIdx.x;
     const long uf = (long)tile * s.NC, ul = uf + s.NC - 1;
-    const long wf = sk_unit_owner(uf, s.U, G), wl = sk_unit_owner(ul, s.U, G);
-    if (wf == wl) return;   // computed by one workgroup: already in y
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    const int k0 = blockIdx.y * KPB;
-    // slot 0: the segment at the START of a workgroup's range, slot 1: the one at its end.  Only the first
-    // contributor can hold this tile at the end of its range (when its range started in an earlier tile); every later
-    // contributor's range starts inside the tile.
-    const int slot_f = (sk_unit_start(wf, s.U, G) / s.NC == tile) ? 0 : 1;
-    float v[KPB];
-    {
-        const float* pp = s.part + ((wf * 2 + slot_f) * NACC + k0) * NT + tid;
-#pragma unroll
-        for (int k = 0; k < KPB; ++k) v[k] = pp[(long)k * NT];
-    }
-    for (long w = wf + 1; w <= wl; ++w) {
-        const float* pp = s.part + ((w * 2) * NACC + k0) * NT + tid;
-#pragma unroll
-        for (int k = 0; k < KPB; ++k) v[k] += pp[(long)k * NT];
-    }
-    const SkTile t_ = sk_decode(s, tile, MT, TW, PH);
-    const float slope = a.act_slope_ptr ? *a.act_slope_ptr : a.act_slope;
-    const long OHW = (long)a.OH * a.OW;
-    float* yn = a.y + (long)t_.n * a.y_bs;
-    const float* rn_ = a.res ? a.res + (long)t_.n * a.res_bs : nullptr;
-    const int pr = l31 / TW, pc = l31 % TW;
-#pragma unroll
-    for (int k = 0; k < KPB; ++k) {
-        const int kk = k0 + k, ij = kk / 16, r = kk % 16, i = ij / RN, j = ij % RN;
-        const int oy = t_.oy0 + (wn * RN + j) * RPT + pr, ox = t_.ox0 + pc;
-        if (oy >= a.OH || ox >= a.OW) continue;
-        const long pix = (long)oy * a.OW + ox;
-        const int co = t_.m0 + (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float o = v[k];
-        if (a.bias) o += a.bias[co];
-        if (rn_) o += rn_[(long)co * OHW + pix];
-        yn[(long)co * OHW + pix] = apply_act(o, a.act, slope);
+    if (sk_unit_owner(uf, s.U, G) == sk_unit_owner(ul, s.U, G)) return;   // computed by one workgroup: already in y
+    switch (blockIdx.y) {
+        case 0: sk_fix_tile<WM, WN, RM, RN, TW, 0 * KPB, KPB>(s, G, tile, threadIdx.x); break;
+        case 1: sk_fix_tile<WM, WN, RM, RN, TW, 1 * KPB, KPB>(s, G, tile, threadIdx.x); break;
+        case 2: sk_fix_tile<WM, WN, RM, RN, TW, 2 * KPB, KPB>(s, G, tile, threadIdx.x); break;
+        default: sk_fix_tile<WM, WN, RM, RN, TW, 3 * KPB, KPB>(s, G, tile, threadIdx.x); break;
     }
 }
 
