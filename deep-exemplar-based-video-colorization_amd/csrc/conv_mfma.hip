@@ -85,8 +85,8 @@ static int conv_num_cus() {
 
 static int g_conv_dbg = 0;
 static long long* g_conv_dbg_buf = nullptr;
-extern "C" void dvc_debug_conv_trace(long long* buf) { g_conv_dbg_buf = buf; }   // not part of the ABI
-extern "C" void dvc_debug_conv_variant(int v) { g_conv_dbg = v; }   // not part of the ABI (timing experiments)
+extern "C" void dvc_debug_conv_trace(long long* buf) { g_conv_dbg_buf = buf; }   // diagnostics (dvc_hip.h, last section)
+extern "C" void dvc_debug_conv_variant(int v) { g_conv_dbg = v; }
 
 extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_packed,
                           const float* bias, const float* in_scale, const float* in_shift,

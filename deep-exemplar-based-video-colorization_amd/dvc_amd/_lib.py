@@ -67,6 +67,11 @@ SIGNATURES = {
                                          _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_size_t, _VP]),
     "dvc_corr_softmax_bwd": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i64, c_i32,
                                             _VP, _VP, _VP, _VP]),
+    # diagnostics for tools/ (include/dvc_hip.h, last section)
+    "dvc_debug_conv_trace": (None, [_VP]),
+    "dvc_debug_conv_variant": (None, [ctypes.c_int]),
+    "dvc_debug_corr_timeline": (None, [_VP, ctypes.c_int]),
+    "dvc_debug_corr_variant": (None, [ctypes.c_int]),
 }
 
 _lib = None

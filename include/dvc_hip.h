@@ -261,6 +261,18 @@ int dvc_corr_softmax_bwd(const float* f_blk, const float* blab, const float* gy,
                          int64_t chan_stride, int32_t ld_t, float* lsum_scratch, float* dS, float* dST,
                          dvcStream stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Diagnostics for the timing probes under tools/ (not needed by any caller of the path; process-global switches, not
+ * thread-safe; all default to off and every probe switches them off again).
+ *   dvc_debug_conv_trace     buf != NULL: LDS-DMA conv kernels record {entry, end of chunk loop, HW_ID, XCC_ID} per workgroup
+ *   dvc_debug_conv_variant   1 / 2 / 3: skip all / patch / weight staging after the first chunk (timing only, wrong results)
+ *   dvc_debug_corr_timeline  buf != NULL: per-tile s_memtime stamps of wave 0 of every correlation workgroup
+ *   dvc_debug_corr_variant   1: skip the softmax arithmetic of dvc_corr_fwd (timing only, wrong results) */
+void dvc_debug_conv_trace(long long* buf);
+void dvc_debug_conv_variant(int v);
+void dvc_debug_corr_timeline(long long* buf, int max_tiles);
+void dvc_debug_corr_variant(int v);
+
 #ifdef __cplusplus
 }
 #endif

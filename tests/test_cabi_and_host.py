@@ -27,6 +27,11 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.SIGNATURES) == set(syms)
     assert lib.dvc_abi_version() == _lib.ABI_VERSION
     assert lib.dvc_corr_workspace_bytes(1, 5184) > 0
+    # ... and nothing with C linkage is exported that the header does not declare
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("dvc_")}
+    assert exported == set(syms), (sorted(exported - set(syms)), sorted(set(syms) - exported))
 
 
 def test_argument_validation_without_gpu():
