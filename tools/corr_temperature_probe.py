@@ -16,14 +16,20 @@ g = torch.Generator().manual_seed(1)
 th = ops.corr_prepare(torch.randn(1, 256, P, generator=g).to(dev))
 ph = ops.corr_prepare(torch.randn(1, 256, P, generator=g).to(dev))
 bl = torch.randn(1, 3, P, generator=g).to(dev)
-for T in (1e-10, 1e-6, 0.005, 0.01, 1.0):
-    for _ in range(3):
+TS = (1e-10, 1e-6, 0.005, 0.01, 1.0)
+for _ in range(150):                      # the first milliseconds of a process run at a lower clock
+    ops.corr_fwd(th, ph, bl, 1e-10, h, w)
+best = {T: float("inf") for T in TS}
+for rnd in range(4):                      # round-robin, min over rounds
+    for T in TS:
         ops.corr_fwd(th, ph, bl, T, h, w)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        ops.corr_fwd(th, ph, bl, T, h, w)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 20 * 1e3
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.corr_fwd(th, ph, bl, T, h, w)
+        e1.record()
+        torch.cuda.synchronize()
+        best[T] = min(best[T], e0.elapsed_time(e1) / 20 * 1e3)
+for T in TS:
+    us = best[T]
     print(f"T = {T:g}: {us:.0f} us  ({13.92e9 / us / 1e6:.1f} TFLOP/s, {13.92e9 / us / 1e6 / 157.3 * 100:.0f} % of fp32 MFMA peak)")
