@@ -3,6 +3,7 @@
 // conv_k3d2.hip, conv_k1.hip and conv_gen.hip.
 #include "conv_kernel.h"
 #include "conv_sk_kernel.h"
+#include "conv_wino_kernel.h"
 
 static int virt_dim(int S, int up, int sub) {
     if (up == 2) return S * 2;
@@ -285,6 +286,110 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
                                a.part, S, (long)d->N * per_img, d->Cout, OHW, bias, residual, a.res_bs, d->act,
                                d->act_slope, act_slope_ptr, y, a.y_bs);
         DVC_CHECK_LAUNCH("dvc_conv2d(split-K reduce)");
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) path (conv_wino_kernel.h) for 3x3 stride-1 layers without a fused input transform.
+extern "C" size_t dvc_winograd_weight_floats(int32_t Cout, int32_t Cin) { return (size_t)Cout * Cin * 16; }
+
+struct WinoShape {
+    int m, tr;   // m: 0 = 128 channels x 32 tiles (4-channel chunks), 1 = 64 channels x 64 tiles (8-channel chunks)
+};
+
+extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const float* u_packed, const float* bias,
+                                   const float* act_slope_ptr, const float* residual, float* y, void* workspace,
+                                   size_t workspace_bytes, dvcStream stream) {
+    DVC_REQUIRE(d && x && u_packed && y, "dvc_conv2d_winograd: null argument");
+    DVC_REQUIRE(d->ksize == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil,
+                "dvc_conv2d_winograd: needs a 3x3 stride-1 layer with pad == dilation (1 or 2)");
+    DVC_REQUIRE(!d->in_prelu, "dvc_conv2d_winograd: no fused input transform on this path");
+    DVC_REQUIRE((d->in_up == 1 || d->in_up == 2) && (d->in_sub == 1 || d->in_sub == 2) && !(d->in_up == 2 && d->in_sub == 2),
+                "dvc_conv2d_winograd: bad in_up/in_sub");
+    DVC_REQUIRE(d->N > 0 && d->Cin > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "dvc_conv2d_winograd: bad shape");
+    DVC_REQUIRE(d->Cin % 8 == 0 && d->Cout % 64 == 0, "dvc_conv2d_winograd: needs Cin %% 8 == 0 and Cout %% 64 == 0 (got %d, %d)",
+                d->Cin, d->Cout);
+    DVC_REQUIRE((reinterpret_cast<uintptr_t>(u_packed) & 15) == 0, "dvc_conv2d_winograd: weights must be 16-byte aligned");
+    DVC_REQUIRE((long)d->Cin * d->H * d->W * 4 < (1L << 31) && (long)d->Cin * 2048 * 4 < (1L << 31),
+                "dvc_conv2d_winograd: tensor too large for buffer-descriptor staging");
+    ConvWinoArgs s;
+    ConvKArgs& a = s.k;
+    a.x = x; a.w = u_packed; a.bias = bias; a.in_scale = nullptr; a.in_shift = nullptr;
+    a.in_slope_ptr = nullptr; a.act_slope_ptr = act_slope_ptr; a.res = residual; a.y = y;
+    a.N = d->N; a.Cin = d->Cin; a.H = d->H; a.W = d->W;
+    a.VH = virt_dim(d->H, d->in_up, d->in_sub);
+    a.VW = virt_dim(d->W, d->in_up, d->in_sub);
+    int32_t OH, OW;
+    dvc_conv2d_out_hw(d, &OH, &OW);
+    DVC_REQUIRE(OH > 0 && OW > 0, "dvc_conv2d_winograd: empty output");
+    if (d->pad_mode == DVC_PAD_REFLECT)
+        DVC_REQUIRE(d->pad < a.VH && d->pad < a.VW, "dvc_conv2d_winograd: reflect pad needs pad < input size");
+    a.Cout = d->Cout; a.OH = OH; a.OW = OW;
+    a.ks = 3; a.stride = 1; a.dil = d->dil; a.pad = d->pad; a.pad_mode = d->pad_mode;
+    a.in_up = d->in_up; a.in_sub = d->in_sub; a.act = d->act; a.in_prelu = 0;
+    a.act_slope = d->act_slope;
+    a.x_bs = d->x_batch_stride ? d->x_batch_stride : (long)d->Cin * d->H * d->W;
+    a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long)d->Cout * OH * OW;
+    a.res_bs = d->res_batch_stride ? d->res_batch_stride : (long)d->Cout * OH * OW;
+    a.cin_pad = d->Cin; a.IH_T = a.IW_T = a.IW_P = 0;
+    a.dbg = g_conv_dbg; a.dbg_buf = nullptr;
+    s.ss = d->dil;
+    const int TY = cdiv(cdiv(OH, s.ss), 2), TX = cdiv(cdiv(OW, s.ss), 2);   // 2x2 tiles of one parity class
+    const int ncu = conv_num_cus();
+    // candidates: workgroup shape m, tile-block shape TR x (32/TR), split S over input-channel chunks; cost in MFMA-times
+    // per SIMD: rounds of workgroups x (chunks x MFMAs per chunk + a per-workgroup prologue/epilogue) + a reduce launch
+    static const int kTR[4] = {1, 2, 4, 8};
+    int best_m = -1, best_tr = 1, best_S = 1;
+    double best_cost = 1e30;
+    for (int m = 0; m < 2; ++m) {
+        const int wm = m == 0 ? 4 : 2, wn = m == 0 ? 1 : 2, kc = m == 0 ? 4 : 8;
+        if (d->Cout % (32 * wm) != 0) continue;
+        if (d->cfg >= 0 && d->cfg / 4 != m) continue;
+        const int nch = d->Cin / kc;
+        for (int ti = 0; ti < 4; ++ti) {
+            const int tr = kTR[ti];
+            if (d->cfg >= 0 && d->cfg % 4 != ti) continue;
+            const long wgs = (long)s.ss * s.ss * cdiv(TY, tr * wn) * cdiv(TX, 32 / tr) * (d->Cout / (32 * wm)) * d->N;
+            for (int S = 1; S <= 8; ++S) {
+                if (d->split_k > 0 && S != d->split_k) continue;
+                if (S > 1 && (!workspace || S > nch / 2 ||
+                              (size_t)S * d->N * d->Cout * OH * OW * sizeof(float) > workspace_bytes)) continue;
+                const int cps = cdiv(nch, S);
+                if (cdiv(nch, cps) != S) continue;
+                const double rounds = (double)cdivl(wgs * S, ncu);
+                double cost = rounds * (cps * (kc / 2) * 16.0 + 160.0) + (S > 1 ? 200.0 : 0.0);
+                cost *= 1.0 + 0.02 * ti;     // wider tile rows store better
+                if (cost < best_cost) { best_cost = cost; best_m = m; best_tr = tr; best_S = S; }
+            }
+        }
+    }
+    DVC_REQUIRE(best_m >= 0, "dvc_conv2d_winograd: no configuration for cfg %d / split_k %d on this layer", d->cfg, d->split_k);
+    const int wm = best_m == 0 ? 4 : 2, wn = best_m == 0 ? 1 : 2, kc = best_m == 0 ? 4 : 8;
+    const int nch = d->Cin / kc;
+    s.blk_y = cdiv(TY, best_tr * wn);
+    s.blk_x = cdiv(TX, 32 / best_tr);
+    a.chunks_per_split = cdiv(nch, best_S);
+    a.split = cdiv(nch, a.chunks_per_split);
+    a.part = reinterpret_cast<float*>(workspace);
+    dim3 grid((unsigned)(s.ss * s.ss * s.blk_y * s.blk_x), (unsigned)(d->Cout / (32 * wm)), (unsigned)(d->N * a.split));
+    hipStream_t st = (hipStream_t)stream;
+    if (best_m == 0 && best_tr == 1 && a.dbg >= 4) conv_wino_launch_m4_dbg(a.dbg, grid, st, s);
+    else if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
+    else conv_wino_launch_m2(best_tr, grid, st, s);
+    DVC_CHECK_LAUNCH("dvc_conv2d_winograd");
+    if (a.split > 1) {
+        const long OHW = (long)OH * OW, per_img = (long)d->Cout * OHW;
+        const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)d->N * per_img) % 4 == 0);
+        if (v4)
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)((per_img / 4 + 255) / 256), d->N), dim3(256), 0, st,
+                               a.part, a.split, (long)d->N * per_img, d->Cout, OHW, bias, residual, a.res_bs, d->act,
+                               d->act_slope, act_slope_ptr, y, a.y_bs);
+        else
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3((unsigned)((per_img + 255) / 256), d->N), dim3(256), 0, st,
+                               a.part, a.split, (long)d->N * per_img, d->Cout, OHW, bias, residual, a.res_bs, d->act,
+                               d->act_slope, act_slope_ptr, y, a.y_bs);
+        DVC_CHECK_LAUNCH("dvc_conv2d_winograd(split-K reduce)");
     }
     return 0;
 }

@@ -150,6 +150,46 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
     return out
 
 
+def pack_winograd_weight(w):
+    """[Cout][Cin][3][3] -> the Winograd F(2x2,3x3) transform-domain filters U = G g G^T in the layout
+    dvc_conv2d_winograd stages, [Cout/32][Cin][4][32][4].  Computed in float64 and rounded once."""
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and co % 32 == 0, w.shape
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64,
+                     device=w.device)
+    U = torch.einsum("ia,ocab,jb->ocij", G, w.detach().double(), G).float()      # [co][ci][4][4]
+    return U.view(co // 32, 32, ci, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def winograd_eligible(Cin, Cout, ksize=3, stride=1, dil=1, pad=1, in_affine=False, in_prelu=False):
+    """Layers dvc_conv2d_winograd takes (include/dvc_hip.h)."""
+    return (ksize == 3 and stride == 1 and dil in (1, 2) and pad == dil and not in_affine and not in_prelu
+            and Cin % 8 == 0 and Cout % 64 == 0)
+
+
+def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1, act=ACT_NONE, act_slope=0.0,
+                    act_slope_t=None, residual=None, out=None, out_batch_stride=0, cfg=-1, split_k=0):
+    """dvc_conv2d_winograd: 3x3, stride 1, pad == dil.  u_packed from pack_winograd_weight."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (u_packed, "u_packed"), (bias, "bias"), (act_slope_t, "act_slope"), (residual, "residual")):
+        _need(t, nm)
+    N, Cin, H, W = x.shape
+    assert u_packed.dim() == 5 and u_packed.shape[1] == Cin and tuple(u_packed.shape[2:]) == (4, 32, 4), u_packed.shape
+    Cout = u_packed.shape[0] * 32
+    OH, OW = conv_out_hw(H, W, 3, 1, dil, dil, in_up, in_sub)
+    if out is None:
+        out = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
+    if residual is not None:
+        assert tuple(residual.shape) == (N, Cout, OH, OW), (residual.shape, (N, Cout, OH, OW))
+    d = DvcConvDesc(N, Cin, H, W, Cout, 3, 1, dil, dil, pad_mode, in_up, in_sub, act, float(act_slope), 0, cfg, split_k,
+                    0, out_batch_stride, 0)
+    ws = _workspace(x.device, CONV_WORKSPACE_BYTES, "conv")
+    rc = lib.dvc_conv2d_winograd(ctypes.byref(d), _p(x), _p(u_packed), _p(bias), _p(act_slope_t), _p(residual), _p(out),
+                                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    _lib.check(rc, "dvc_conv2d_winograd")
+    return out
+
+
 if _autotune:
     _load_tuned()  # env-enabled autotune: pick up a persisted table
 

@@ -27,7 +27,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 5
+#define DVC_ABI_VERSION 6
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -99,6 +99,22 @@ int dvc_conv2d(const DvcConvDesc* d,
                const float* residual /* or NULL */, float* y,
                void* workspace /* or NULL: scratch for split-K partial sums */, size_t workspace_bytes,
                dvcStream stream);
+
+/* The same 3x3 convolution (every 3x3 stride-1 nn.Conv2d of models/ColorVidNet.py:14-81, models/NonlocalNet.py:200-215,
+ * 330-339, 359-420 whose input needs no fused per-element transform) in Winograd F(2x2,3x3) form: 2.25x fewer
+ * multiplies, fp32 throughout, result within fp32 rounding of the direct sum (what cuDNN selects for these layers under
+ * the reference's cudnn.benchmark = True, test.py:140).  Requirements: ksize 3, stride 1, dil 1|2 with pad == dil,
+ * Cin % 8 == 0, Cout % 64 == 0, in_prelu == 0.  Descriptor fields as for dvc_conv2d except
+ *   cfg      -1 = automatic | tile-block shape (0: 1x32, 1: 2x16, 2: 4x8, 3: 8x4 tiles) + 4 * workgroup shape
+ *            (0: 128 channels x 32 tiles, 1: 64 channels x 64 tiles)
+ *   split_k  0 = automatic | 1..8 = split over input-channel chunks (needs the workspace, as dvc_conv2d)
+ * u_packed: the filters in the transform domain, U = G g G^T, laid out [Cout/32][Cin][4][32][4]
+ * (dvc_winograd_weight_floats(Cout, Cin) floats; the Python side builds it in float64 and rounds once). */
+size_t dvc_winograd_weight_floats(int32_t Cout, int32_t Cin);
+int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const float* u_packed,
+                        const float* bias /* may be NULL */, const float* act_slope_ptr /* device scalar or NULL */,
+                        const float* residual /* or NULL */, float* y,
+                        void* workspace /* or NULL */, size_t workspace_bytes, dvcStream stream);
 
 /* conv 1x1 with tiny Cout (<= 4) + optional tanh*128: ColorVidNet.conv10_ab, ColorVidNet.py:142-144.
  * w is the unpacked [Cout][Cin] matrix. */

@@ -203,6 +203,60 @@ def test_conv2d_stream_k(ops, case, cfg, per_cu):
     assert (big[:, :8] == 3).all() and (big[:, 8 + Cout:] == 3).all()
 
 
+WINO_CASES = [
+    # name, N, Cin, Cout, H, W, dil, pad_mode, in_up, in_sub, res, act
+    ("wn_small", 1, 8, 64, 20, 36, 1, 0, 1, 1, True, 1),                 # one or two chunks
+    ("wn_odd", 2, 24, 64, 13, 23, 1, 0, 1, 1, False, 3),                 # odd H and W: half tiles on both edges, batch 2
+    ("wn_up_res", 1, 32, 128, 13, 24, 1, 0, 2, 1, True, 1),
+    ("wn_sub", 1, 16, 64, 54, 96, 1, 0, 1, 2, False, 1),
+    ("wn_reflect", 1, 64, 128, 30, 40, 1, 1, 1, 1, False, 0),
+    ("wn_dil2", 2, 32, 64, 27, 48, 2, 0, 1, 1, False, 1),                # four parity classes, odd H
+    ("wn_dil2_odd", 1, 16, 128, 21, 37, 2, 0, 1, 1, True, 0),
+    # network shapes
+    ("wn_res_trunk", 1, 256, 256, 54, 96, 1, 1, 1, 1, False, 0),
+    ("wn_vgg5", 1, 512, 512, 13, 24, 1, 0, 1, 1, False, 1),
+    ("wn_cvn_27", 1, 512, 512, 27, 48, 1, 0, 1, 1, False, 1),
+    ("wn_cvn_d2", 1, 512, 512, 27, 48, 2, 0, 1, 1, False, 1),
+    ("wn_cvn_up", 1, 256, 128, 54, 96, 1, 0, 2, 1, True, 1),
+    ("wn_full_res", 1, 64, 64, 216, 384, 1, 0, 1, 1, False, 1),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
+@pytest.mark.parametrize("cfg,split_k", [(-1, 0), (0, 1), (1, 2), (2, 1), (3, 3), (4, 1), (5, 2), (6, 0), (7, 1)])
+def test_conv2d_winograd(ops, case, cfg, split_k):
+    """Winograd F(2x2,3x3) path (every tile-block shape x both workgroup shapes, with and without the split over input
+    channels): the fp64 reference at a tolerance ~2.5x the direct engine's (the transform's known rounding), deterministic,
+    destination may be a channel slice, bytes around the destination untouched."""
+    (name, N, Cin, Cout, H, W, dil, pad_mode, in_up, in_sub, use_res, act) = case
+    if cfg >= 0 and cfg // 4 == 0 and Cout % 128:
+        pytest.skip("Cout not a multiple of the 128-channel workgroup shape")
+    if split_k > 1 and split_k > (Cin // (4 if cfg < 4 else 8)) // 2:
+        pytest.skip("fewer than two chunks per split")
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    OH, OW = ops.conv_out_hw(H, W, 3, 1, dil, dil, in_up, in_sub)
+    res = torch.randn(N, Cout, OH, OW, generator=g) if use_res else None
+    ref = ref_conv(x, w, b, 3, 1, dil, dil, pad_mode, in_up, in_sub, None, None, None, res, act, 0.2)
+    big = torch.full((N, Cout + 16, OH, OW), 3.0, device="cuda")
+    kw = dict(dil=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, act=act, act_slope=0.2,
+              residual=None if res is None else res.cuda(), out=big[:, 8:8 + Cout],
+              out_batch_stride=(Cout + 16) * OH * OW, cfg=cfg, split_k=split_k)
+    xd, ud, bd = x.cuda(), ops.pack_winograd_weight(w.cuda()), b.cuda()
+    ops.conv2d_winograd(xd, ud, bd, **kw)
+    y1 = big[:, 8:8 + Cout].clone()
+    big[:, 8:8 + Cout] = -7.0
+    ops.conv2d_winograd(xd, ud, bd, **kw)
+    torch.cuda.synchronize()
+    e = relerr(y1, ref)
+    report(f"conv2d winograd {name} cfg={cfg} split={split_k}: rel_err={e:.3e}")
+    assert e < 5e-5, (name, cfg, split_k, e)
+    assert torch.equal(y1, big[:, 8:8 + Cout])               # deterministic, every element rewritten
+    assert (big[:, :8] == 3).all() and (big[:, 8 + Cout:] == 3).all()
+
+
 def test_conv2d_channel_slice_output(ops):
     """y may be a channel slice of a wider tensor (WarpNet concat, NonlocalNet.py:464)."""
     g = torch.Generator().manual_seed(5)
