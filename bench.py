@@ -394,6 +394,11 @@ def main():
                        "correlation": "fp32 MFMA" if args.corr == "fp32" else
                        "bf16 MFMA candidate filter + exact fp32 re-scoring (configs[4])",
                        "exemplar_side": "recomputed per frame" if args.no_exemplar_cache else "cached per clip",
+                       "conv_algorithm": {"auto": "Winograd F(2x2,3x3) on the fp32 matrix cores where ops.winograd_selected "
+                                                  "picks it (3x3 stride-1 layers with >= 27x48 outputs), direct "
+                                                  "implicit GEMM elsewhere; fp32 throughout",
+                                          "winograd": "Winograd F(2x2,3x3) on every eligible 3x3 layer",
+                                          "direct": "direct implicit GEMM everywhere"}[ops.conv_algo()],
                        "conv_tile_choice": "static cost model" if args.no_autotune else
                        "autotuned on first use during warm-up (cf. cudnn.benchmark=True, test.py:140)",
                        "frames_per_gpu": K, "parallelism": f"frame-chunks x{n_gpus}",

@@ -46,6 +46,24 @@ class _PackCache:
         return hit[1]
 
 
+def _packs(cache, key, weight):
+    """kind -> packed weight of one 3x3 layer: "direct" = [Cin][9][Cout], "winograd" = U = G g G^T (ops.conv3x3)."""
+    def get(kind):
+        if kind == "winograd":
+            return cache.get(key + ":wino", weight, ops.pack_winograd_weight)
+        return cache.get(key, weight, ops.pack_conv_weight)
+    return get
+
+
+def _prepack(cache, key, conv):
+    """Both packed forms a 3x3 layer may be asked for under the current algorithm choice (ops.set_conv_algo)."""
+    get = _packs(cache, key, conv.weight)
+    get("direct")
+    co, ci, kh, kw = conv.weight.shape
+    if ops.conv_algo() != "direct" and conv.stride[0] == 1 and ops.winograd_eligible(ci, co, kh):
+        get("winograd")
+
+
 def _check_input(x, name):
     if not x.is_cuda:
         raise RuntimeError(f"{name}: input is on {x.device}; the MI355X HIP path has no CPU fallback "
@@ -90,7 +108,7 @@ class VGG19_pytorch(nn.Module):
     def prepare(self):
         """Pack every weight now, on the current stream (see _PackCache.get)."""
         for name, _, _ in arch.VGG_CONVS:
-            self._packed(name)
+            _prepack(self._cache, name, getattr(self, name))
         self._packed("conv1_1", swap_bgr=True)
         self._pre_affine()
 
@@ -120,7 +138,7 @@ class VGG19_pytorch(nn.Module):
                     cur = ops.conv2d(cur, self._packed(name, swap_bgr=True), bias, act=ops.ACT_RELU,
                                      in_scale=sc.repeat(N), in_shift=sh.repeat(N))
                 else:
-                    cur = ops.conv2d(cur, self._packed(name), bias, act=ops.ACT_RELU)
+                    cur = ops.conv3x3(cur, conv.weight, _packs(self._cache, name, conv.weight), bias, act=ops.ACT_RELU)
             out[key] = cur
         return [out[key] for key in out_keys]
 
@@ -173,15 +191,18 @@ class WarpNet(nn.Module):
     def _pk(self, key, conv):
         return self._cache.get(key, conv.weight, ops.pack_conv_weight)
 
+    def _conv3(self, key, conv, x, **kw):
+        return ops.conv3x3(x, conv.weight, _packs(self._cache, key, conv.weight), conv.bias.detach(), **kw)
+
     def prepare(self):
         """Pack every weight now, on the current stream (see _PackCache.get)."""
         for name in arch.WARP_HEAD_ORDER:
             seq = getattr(self, name)
             for (ci, _, _, _, _) in arch.WARP_HEADS[name]["convs"]:
-                self._pk(f"{name}.{ci}", seq[ci])
+                _prepack(self._cache, f"{name}.{ci}", seq[ci])
         for b in range(arch.WARP_NUM_RESBLOCKS):
-            self._pk(f"layer.{b}.conv1", self.layer[b].conv1)
-            self._pk(f"layer.{b}.conv2", self.layer[b].conv2)
+            _prepack(self._cache, f"layer.{b}.conv1", self.layer[b].conv1)
+            _prepack(self._cache, f"layer.{b}.conv2", self.layer[b].conv2)
         self._pk("theta", self.theta)
         self._pk("phi", self.phi)
 
@@ -218,14 +239,13 @@ class WarpNet(nn.Module):
             seq = getattr(self, name)
             (ia, _, _, _, pa), (ib, _, _, sb, pb) = spec["convs"]
             ca, cb = seq[ia], seq[ib]
-            t = ops.conv2d(x, self._pk(f"{name}.{ia}", ca), ca.bias.detach(), pad_mode=ops.PAD_REFLECT)
+            t = self._conv3(f"{name}.{ia}", ca, x, pad_mode=ops.PAD_REFLECT)
             # InstanceNorm + PReLU are materialised (one launch, in place) so that the next convolution
             # has no fused input transform and stages through LDS-DMA; the stride-2 convolution
             # (run-time-geometry kernel, register staging anyway) applies them on load instead
             if sb == 1:
                 ops.instnorm_apply(t, slope_t=seq[pa].weight.detach(), out=t)
-                t = ops.conv2d(t, self._pk(f"{name}.{ib}", cb), cb.bias.detach(), pad_mode=ops.PAD_REFLECT,
-                               in_up=2 if spec["up_mid"] else 1)
+                t = self._conv3(f"{name}.{ib}", cb, t, pad_mode=ops.PAD_REFLECT, in_up=2 if spec["up_mid"] else 1)
             else:
                 sc, sh = ops.instnorm_stats(t)
                 t = ops.conv2d(t, self._pk(f"{name}.{ib}", cb), cb.bias.detach(), stride=sb,
@@ -238,11 +258,9 @@ class WarpNet(nn.Module):
         for b in range(arch.WARP_NUM_RESBLOCKS):
             blk = self.layer[b]
             a = blk.prelu.weight.detach()
-            t = ops.conv2d(x, self._pk(f"layer.{b}.conv1", blk.conv1), blk.conv1.bias.detach(),
-                           pad_mode=ops.PAD_REFLECT)
+            t = self._conv3(f"layer.{b}.conv1", blk.conv1, x, pad_mode=ops.PAD_REFLECT)
             ops.instnorm_apply(t, slope_t=a, out=t)
-            t = ops.conv2d(t, self._pk(f"layer.{b}.conv2", blk.conv2), blk.conv2.bias.detach(),
-                           pad_mode=ops.PAD_REFLECT)
+            t = self._conv3(f"layer.{b}.conv2", blk.conv2, t, pad_mode=ops.PAD_REFLECT)
             x = ops.instnorm_apply(t, residual=x, slope_t=a, out=t)
         return x
 
@@ -355,7 +373,7 @@ class ColorVidNet(nn.Module):
     def prepare(self):
         """Pack every weight now, on the current stream (see _PackCache.get)."""
         for c in arch.CVN_CONVS:
-            self._cache.get(c["key"], self._mod(c["key"]).weight, ops.pack_conv_weight)
+            _prepack(self._cache, c["key"], self._mod(c["key"]))
             if c["pre"] == "norm_ss":
                 self._ss_weight(c["ss"])
         self._out_weight()
@@ -389,8 +407,7 @@ class ColorVidNet(nn.Module):
         act_map = {"relu": ops.ACT_RELU, "none": ops.ACT_NONE, "leaky": ops.ACT_LEAKY}
         for c in arch.CVN_CONVS:
             conv = self._mod(c["key"])
-            wp = self._cache.get(c["key"], conv.weight, ops.pack_conv_weight)
-            kw = dict(dil=c["dil"], pad=c["dil"], act=act_map[c["act"]], act_slope=0.2)
+            kw = dict(dil=c["dil"], act=act_map[c["act"]], act_slope=0.2)
             pre = c["pre"]
             src = acts[c["src"]]
             if pre == "norm":
@@ -402,6 +419,6 @@ class ColorVidNet(nn.Module):
                 kw["in_up"] = 2
             if c["add"] is not None:
                 kw["residual"] = acts[c["add"]]
-            acts[c["dst"]] = ops.conv2d(src, wp, conv.bias.detach(), **kw)
+            acts[c["dst"]] = ops.conv3x3(src, conv.weight, _packs(self._cache, c["key"], conv.weight), conv.bias.detach(), **kw)
         out = self._mod(arch.CVN_OUT["key"])
         return ops.conv1x1_small(acts["c10_2"], self._out_weight(), out.bias.detach(), act=ops.ACT_TANH128)

@@ -183,11 +183,65 @@ def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_
         assert tuple(residual.shape) == (N, Cout, OH, OW), (residual.shape, (N, Cout, OH, OW))
     d = DvcConvDesc(N, Cin, H, W, Cout, 3, 1, dil, dil, pad_mode, in_up, in_sub, act, float(act_slope), 0, cfg, split_k,
                     0, out_batch_stride, 0)
+    if conv_record is not None:
+        conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=3, stride=1, dil=dil, pad=dil, pad_mode=pad_mode,
+                                in_up=in_up, in_sub=in_sub, affine=False, in_prelu=False, residual=residual is not None,
+                                act=act, algo="winograd"))
     ws = _workspace(x.device, CONV_WORKSPACE_BYTES, "conv")
     rc = lib.dvc_conv2d_winograd(ctypes.byref(d), _p(x), _p(u_packed), _p(bias), _p(act_slope_t), _p(residual), _p(out),
                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     _lib.check(rc, "dvc_conv2d_winograd")
     return out
+
+
+# ---- algorithm choice for the 3x3 stride-1 layers.  "direct": the implicit-GEMM engine everywhere; "winograd": the
+# F(2x2,3x3) kernel on every layer it takes; "auto" (default): the static rule below, fitted to
+# profiles/r02_conv_wino_probe.txt (Winograd where it is measured faster).  The choice is a pure function of the layer
+# geometry, so the clip driver's pipelined and sequential orders still run the same kernels (bit-identical outputs).
+_conv_algo = _os.environ.get("DVC_CONV_ALGO", "auto")
+
+
+def set_conv_algo(algo):
+    global _conv_algo
+    if algo not in ("auto", "direct", "winograd"):
+        raise ValueError("conv algo must be 'auto', 'direct' or 'winograd'")
+    _conv_algo = algo
+
+
+def conv_algo():
+    return _conv_algo
+
+
+def winograd_selected(N, Cin, H, W, Cout, *, ksize=3, stride=1, dil=1, pad=1, in_up=1, in_sub=1, in_affine=False,
+                      in_prelu=False):
+    """True if the current algorithm choice sends this layer to dvc_conv2d_winograd."""
+    if _conv_algo == "direct" or not winograd_eligible(Cin, Cout, ksize, stride, dil, pad, in_affine, in_prelu):
+        return False
+    if _conv_algo == "winograd":
+        return True
+    OH, OW = conv_out_hw(H, W, ksize, stride, dil, pad, in_up, in_sub)
+    return _wino_rule(N, Cin, Cout, OH, OW, dil)
+
+
+def _wino_rule(N, Cin, Cout, OH, OW, dil):
+    # measured on the MI355X (profiles/r02_conv_wino_probe.txt): Winograd wins wherever the layer has enough 2x2 tiles
+    # to fill the chip after the split over input channels; the 13x24 VGG block-5 layers stay on the direct engine
+    return N * OH * OW >= 27 * 48
+
+
+def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1, act=ACT_NONE, act_slope=0.0,
+            act_slope_t=None, residual=None, out=None, out_batch_stride=0):
+    """A 3x3 stride-1 pad == dil layer through whichever engine the algorithm choice selects.  `packs(kind)` returns
+    the packed weight for kind "direct" ([Cin][9][Cout]) or "winograd" (U = G g G^T), normally from a _PackCache."""
+    N, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    if winograd_selected(N, Cin, H, W, Cout, dil=dil, pad=dil, in_up=in_up, in_sub=in_sub):
+        return conv2d_winograd(x, packs("winograd"), bias, dil=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub,
+                               act=act, act_slope=act_slope, act_slope_t=act_slope_t, residual=residual, out=out,
+                               out_batch_stride=out_batch_stride)
+    return conv2d(x, packs("direct"), bias, dil=dil, pad=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, act=act,
+                  act_slope=act_slope, act_slope_t=act_slope_t, residual=residual, out=out,
+                  out_batch_stride=out_batch_stride)
 
 
 if _autotune:
