@@ -3,7 +3,7 @@
 // conv_k3d2.hip, conv_k1.hip and conv_gen.hip.
 #include "conv_kernel.h"
 #include "conv_sk_kernel.h"
-#include "conv_wino2_kernel.h"
+#include "conv_wino_kernel.h"
 
 static int virt_dim(int S, int up, int sub) {
     if (up == 2) return S * 2;
@@ -342,7 +342,7 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
     static const int kTR[4] = {1, 2, 4, 8};
     int best_m = -1, best_tr = 1, best_S = 1;
     double best_cost = 1e30;
-    const int shape_cfg = (d->cfg >= 0 && !(d->cfg & 8)) ? (d->cfg & 7) : -1;      // cfg bit 3: automatic shape
+    const int shape_cfg = d->cfg >= 0 ? (d->cfg & 7) : -1;
     for (int m = 0; m < 2; ++m) {
         const int wm = m == 0 ? 4 : 2, wn = m == 0 ? 1 : 2, kc = m == 0 ? 4 : 8;
         if (d->Cout % (32 * wm) != 0) continue;
@@ -375,14 +375,7 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
     a.part = reinterpret_cast<float*>(workspace);
     dim3 grid((unsigned)(s.ss * s.ss * s.blk_y * s.blk_x), (unsigned)(d->Cout / (32 * wm)), (unsigned)(d->N * a.split));
     hipStream_t st = (hipStream_t)stream;
-    // two kernels for the same decomposition: position-split (two waves per SIMD; the default) and the one-wave-per-SIMD
-    // form (cfg 16 + k, or the timing-experiment variants of dvc_debug_conv_variant)
-    const bool one_wave = (d->cfg >= 16) || a.dbg >= 4;
-    if (!one_wave) {
-        if (best_m == 0) conv_wino2_launch_m4(best_tr, grid, st, s);
-        else conv_wino2_launch_m2(best_tr, grid, st, s);
-    } else if (best_m == 0 && best_tr == 1 && a.dbg >= 4) conv_wino_launch_m4_dbg(a.dbg, grid, st, s);
-    else if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
+    if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
     else conv_wino_launch_m2(best_tr, grid, st, s);
     DVC_CHECK_LAUNCH("dvc_conv2d_winograd");
     if (a.split > 1) {

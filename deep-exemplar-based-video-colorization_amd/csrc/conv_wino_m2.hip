@@ -1,4 +1,4 @@
-// Instantiations of the Winograd conv kernel template: 64 output channels x 64 tiles per workgroup, 8-channel chunks.
+// Instantiations of the Winograd conv kernel template: 64 output channels x 64 tiles per workgroup (8 waves), 8-channel chunks.
 #include "conv_wino_kernel.h"
 
 void conv_wino_launch_m2(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s) {

@@ -106,8 +106,7 @@ int dvc_conv2d(const DvcConvDesc* d,
  * the reference's cudnn.benchmark = True, test.py:140).  Requirements: ksize 3, stride 1, dil 1|2 with pad == dil,
  * Cin % 8 == 0, Cout % 64 == 0, in_prelu == 0.  Descriptor fields as for dvc_conv2d except
  *   cfg      -1 = automatic | tile-block shape (0: 1x32, 1: 2x16, 2: 4x8, 3: 8x4 tiles) + 4 * workgroup shape
- *            (0: 128 channels x 32 tiles, 1: 64 channels x 64 tiles) [+ 8: shape automatic] [+ 16: the kernel with one
- *            wave per SIMD and all 16 transform positions per wave instead of the position-split one with two]
+ *            (0: 128 channels x 32 tiles, 1: 64 channels x 64 tiles)
  *   split_k  0 = automatic | 1..8 = split over input-channel chunks (needs the workspace, as dvc_conv2d)
  * u_packed: the filters in the transform domain, U = G g G^T, laid out [Cout/32][Cin][4][32][4]
  * (dvc_winograd_weight_floats(Cout, Cin) floats; the Python side builds it in float64 and rounds once). */

@@ -3,7 +3,6 @@
 Records the convolution launches of one frame (ClipColorizer.frame), then times each distinct layer geometry under
   direct   ops.conv2d, library's static tile choice
   wino     ops.conv2d_winograd, library's cost model (position-split kernel, two waves per SIMD)
-  wino1    the same with the one-wave-per-SIMD kernel (cfg 24)
 round-robin after a clock warm-up (min over rounds), and prints per-frame totals for: direct everywhere, Winograd on every
 eligible layer, the static rule of ops.winograd_selected ("auto"), and the best of the two per layer.
 Writes gpurun_out/conv_algo_sweep.json.   TUNE_H / TUNE_W select the frame size (default 216x384)."""
@@ -81,8 +80,6 @@ for k, (r, count) in uniq.items():
         up = ops.pack_winograd_weight(w)
         cands["wino"] = lambda: ops.conv2d_winograd(x, up, b, dil=r["dil"], pad_mode=r["pad_mode"], in_up=r["in_up"],
                                                      in_sub=r["in_sub"], act=r["act"], act_slope=0.2, residual=res)
-        cands["wino1"] = lambda: ops.conv2d_winograd(x, up, b, dil=r["dil"], pad_mode=r["pad_mode"], in_up=r["in_up"],
-                                                      in_sub=r["in_sub"], act=r["act"], act_slope=0.2, residual=res, cfg=24)
         yd, yw = cands["direct"](), cands["wino"]()
         err = ((yd - yw).abs().max() / yd.abs().max()).item()
     for _ in range(40):
@@ -101,10 +98,9 @@ for k, (r, count) in uniq.items():
     tot["auto"] += count * (tw if sel else td)
     tot["best"] += count * min(td, tw)
     gf_tot += count * gf
-    rows.append(dict(layer=r, count=count, gflop=gf, us_direct=td, us_wino=best.get("wino"), us_wino_one_wave=best.get("wino1"),
-                     auto_is_wino=bool(sel), rel_diff=err))
+    rows.append(dict(layer=r, count=count, gflop=gf, us_direct=td, us_wino=best.get("wino"), auto_is_wino=bool(sel), rel_diff=err))
     print(f"x{count} {r['Cin']:4d}->{r['Cout']:4d} k{r['ksize']} s{r['stride']} d{r['dil']} {r['H']:3d}x{r['W']:3d} up{r['in_up']} sub{r['in_sub']} "
-          f"{gf:6.2f} GF: direct {td:6.1f} us" + (f", wino {tw:6.1f} us ({gf / tw * 1e3:5.1f} TF eff; one wave/SIMD {best['wino1']:6.1f}), auto={'wino' if sel else 'direct'}, "
+          f"{gf:6.2f} GF: direct {td:6.1f} us" + (f", wino {tw:6.1f} us ({gf / tw * 1e3:5.1f} TF eff), auto={'wino' if sel else 'direct'}, "
                                                    f"|diff|/max = {err:.1e}" if elig else " (not eligible)"), flush=True)
 print(f"per frame, {gf_tot:.1f} GFLOP of convolutions: " + ", ".join(f"{k} {v / 1e3:.3f} ms ({gf_tot / v * 1e3:.1f} TF)" for k, v in tot.items()))
 os.makedirs("gpurun_out", exist_ok=True)

@@ -30,5 +30,14 @@ for (ci, co, H, W, dil, cfg, sk) in shapes:
     b = torch.randn(co, device=dev)
     for _ in range(3):
         ops.conv2d(x, wt, b, dil=dil, pad=dil, act=1, cfg=cfg, split_k=sk)
+# Winograd F(2x2,3x3) kernel (library's own shape / split choice) on the layer shapes that carry the frame
+for (ci, co, H, W, dil, up) in [(256, 256, 54, 96, 1, 1), (512, 512, 27, 48, 1, 1), (512, 512, 27, 48, 2, 1),
+                                (128, 128, 108, 192, 1, 1), (64, 64, 216, 384, 1, 1), (128, 128, 216, 384, 1, 1),
+                                (128, 128, 108, 192, 1, 2)]:
+    x = torch.randn(1, ci, H, W, device=dev)
+    u = ops.pack_winograd_weight(torch.randn(co, ci, 3, 3, device=dev) * 0.05)
+    b = torch.randn(co, device=dev)
+    for _ in range(3):
+        ops.conv2d_winograd(x, u, b, dil=dil, in_up=up, act=1)
 torch.cuda.synchronize()
 print("done")

@@ -47,7 +47,7 @@ lines = ["# PMC summary (" + tag + ")", "",
          "| kernel | us | clock GHz | waves | MFMA util | per-wave kcycles: alive / own-MFMA / active / wait-inst / wait-any | VALU/wave | LDS bank-conflict cyc | HBM read MB (2xFETCH) | HBM write MB |",
          "|---|---|---|---|---|---|---|---|---|---|"]
 for k, v in agg.items():
-    if "conv_mfma" not in k and "corr_fwd" not in k and "conv_sk_kernel" not in k:
+    if "conv_mfma" not in k and "corr_fwd" not in k and "conv_sk_kernel" not in k and "conv_wino" not in k:
         continue
     c = {n: sum(x) / len(x) for n, x in v.items()}
     if "GRBM_GUI_ACTIVE" not in c:
@@ -56,7 +56,7 @@ for k, v in agg.items():
     cyc = c["GRBM_GUI_ACTIVE"] / 8
     w = c["SQ_WAVES"]
     lines.append("| `%s` | %.0f | %.2f | %d | %.1f%% | %.0f / %.0f / %.0f / %.0f / %.0f | %.0f | %.0f | %.1f | %.1f |" % (
-        k.replace("void ", "").replace("(ConvKArgs)", "").replace("(CorrArgs)", "").replace("(ConvSkArgs)", ""), us, cyc / us / 1e3, w,
+        k.replace("void ", "").replace("(ConvKArgs)", "").replace("(CorrArgs)", "").replace("(ConvSkArgs)", "").replace("(ConvWinoArgs)", ""), us, cyc / us / 1e3, w,
         100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), c["SQ_WAVE_CYCLES"] * 4 / w / 1e3,
         c["SQ_VALU_MFMA_BUSY_CYCLES"] / w / 1e3, c["SQ_ACTIVE_INST_ANY"] * 4 / w / 1e3,
         c["SQ_WAIT_INST_ANY"] * 4 / w / 1e3, c.get("SQ_WAIT_ANY", 0) * 4 / w / 1e3, c.get("SQ_INSTS_VALU", 0) / w,
