@@ -294,9 +294,41 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
 // Winograd F(2x2,3x3) path (conv_wino_kernel.h) for 3x3 stride-1 layers without a fused input transform.
 extern "C" size_t dvc_winograd_weight_floats(int32_t Cout, int32_t Cin) { return (size_t)Cout * Cin * 16; }
 
-struct WinoShape {
-    int m, tr;   // m: 0 = 128 channels x 32 tiles (4-channel chunks), 1 = 64 channels x 64 tiles (8-channel chunks)
-};
+// U = G g G^T per (output channel, input channel), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], evaluated in double and rounded
+// once; thread = one (co, ci) pair, output layout [co / 32][ci][i][co % 32][j]
+__global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ u) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)Cout * Cin) return;
+    const int ci = (int)(e / Cout), co = (int)(e % Cout);     // consecutive threads: consecutive co (16-byte stores side by side)
+    const float* g = w + ((long)co * Cin + ci) * 9;
+    double t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const double g0 = g[b], g1 = g[3 + b], g2 = g[6 + b];
+        t[0][b] = g0;
+        t[1][b] = 0.5 * (g0 + g1 + g2);
+        t[2][b] = 0.5 * (g0 - g1 + g2);
+        t[3][b] = g2;
+    }
+    float* dst = u + (((long)(co / 32) * Cin + ci) * 4 * 32 + (co % 32)) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double a = t[i][0], b = t[i][1], c = t[i][2];
+        *reinterpret_cast<float4*>(dst + (long)i * 32 * 4) =
+            make_float4((float)a, (float)(0.5 * (a + b + c)), (float)(0.5 * (a - b + c)), (float)c);
+    }
+}
+
+extern "C" int dvc_winograd_pack_weight(const float* w, int32_t Cout, int32_t Cin, float* u_packed, dvcStream stream) {
+    DVC_REQUIRE(w && u_packed, "dvc_winograd_pack_weight: null argument");
+    DVC_REQUIRE(Cout > 0 && Cin > 0 && Cout % 32 == 0, "dvc_winograd_pack_weight: needs Cout %% 32 == 0 (got %d)", Cout);
+    DVC_REQUIRE((reinterpret_cast<uintptr_t>(u_packed) & 15) == 0, "dvc_winograd_pack_weight: destination must be 16-byte aligned");
+    const long n = (long)Cout * Cin;
+    hipLaunchKernelGGL(wino_pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin,
+                       u_packed);
+    DVC_CHECK_LAUNCH("dvc_winograd_pack_weight");
+    return 0;
+}
 
 extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const float* u_packed, const float* bias,
                                    const float* act_slope_ptr, const float* residual, float* y, void* workspace,
@@ -373,7 +405,11 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
     a.chunks_per_split = cdiv(nch, best_S);
     a.split = cdiv(nch, a.chunks_per_split);
     a.part = reinterpret_cast<float*>(workspace);
-    dim3 grid((unsigned)(s.ss * s.ss * s.blk_y * s.blk_x), (unsigned)(d->Cout / (32 * wm)), (unsigned)(d->N * a.split));
+    s.gx = s.ss * s.ss * s.blk_y * s.blk_x;
+    s.gy = d->Cout / (32 * wm);
+    s.gz = d->N * a.split;
+    DVC_REQUIRE((long)s.gx * s.gy * s.gz < (1L << 31), "dvc_conv2d_winograd: grid too large");
+    dim3 grid((unsigned)(s.gx * s.gy * s.gz));      // 1-D: the kernel maps it XCD-aware onto (gx, gy, gz)
     hipStream_t st = (hipStream_t)stream;
     if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
     else conv_wino_launch_m2(best_tr, grid, st, s);

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvc_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -35,6 +35,7 @@ SIGNATURES = {
     "dvc_conv2d": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                   ctypes.c_size_t, _VP]),
     "dvc_winograd_weight_floats": (ctypes.c_size_t, [c_i32, c_i32]),
+    "dvc_winograd_pack_weight": (ctypes.c_int, [_VP, c_i32, c_i32, _VP, _VP]),
     "dvc_conv2d_winograd": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                            ctypes.c_size_t, _VP]),
     "dvc_conv1x1_small": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, _VP, _VP]),

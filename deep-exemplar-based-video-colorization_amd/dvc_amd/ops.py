@@ -152,13 +152,16 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
 
 def pack_winograd_weight(w):
     """[Cout][Cin][3][3] -> the Winograd F(2x2,3x3) transform-domain filters U = G g G^T in the layout
-    dvc_conv2d_winograd stages, [Cout/32][Cin][4][32][4].  Computed in float64 and rounded once."""
+    dvc_conv2d_winograd stages, [Cout/32][Cin][4][32][4] (dvc_winograd_pack_weight: evaluated in double, rounded once)."""
+    lib = _lib.load()
+    w = w.detach()
+    _need(w, "weight")
     co, ci, kh, kw = w.shape
     assert (kh, kw) == (3, 3) and co % 32 == 0, w.shape
-    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64,
-                     device=w.device)
-    U = torch.einsum("ia,ocab,jb->ocij", G, w.detach().double(), G).float()      # [co][ci][4][4]
-    return U.view(co // 32, 32, ci, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+    u = torch.empty((co // 32, ci, 4, 32, 4), device=w.device, dtype=torch.float32)
+    assert u.numel() == lib.dvc_winograd_weight_floats(co, ci)
+    _lib.check(lib.dvc_winograd_pack_weight(_p(w), co, ci, _p(u), _stream()), "dvc_winograd_pack_weight")
+    return u
 
 
 def winograd_eligible(Cin, Cout, ksize=3, stride=1, dil=1, pad=1, in_affine=False, in_prelu=False):

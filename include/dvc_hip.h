@@ -27,7 +27,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 6
+#define DVC_ABI_VERSION 7
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -109,8 +109,11 @@ int dvc_conv2d(const DvcConvDesc* d,
  *            (0: 128 channels x 32 tiles, 1: 64 channels x 64 tiles)
  *   split_k  0 = automatic | 1..8 = split over input-channel chunks (needs the workspace, as dvc_conv2d)
  * u_packed: the filters in the transform domain, U = G g G^T, laid out [Cout/32][Cin][4][32][4]
- * (dvc_winograd_weight_floats(Cout, Cin) floats; the Python side builds it in float64 and rounds once). */
+ * (dvc_winograd_weight_floats(Cout, Cin) floats, written by dvc_winograd_pack_weight). */
 size_t dvc_winograd_weight_floats(int32_t Cout, int32_t Cin);
+/* w: [Cout][Cin][3][3] (the nn.Conv2d weight as stored in the reference's checkpoints) -> u_packed, evaluated in double
+ * and rounded once.  Cout % 32 == 0. */
+int dvc_winograd_pack_weight(const float* w, int32_t Cout, int32_t Cin, float* u_packed, dvcStream stream);
 int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const float* u_packed,
                         const float* bias /* may be NULL */, const float* act_slope_ptr /* device scalar or NULL */,
                         const float* residual /* or NULL */, float* y,

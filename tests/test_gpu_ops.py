@@ -222,6 +222,22 @@ WINO_CASES = [
 ]
 
 
+def test_winograd_pack_weight(ops):
+    """dvc_winograd_pack_weight against U = G g G^T evaluated in float64 (exactly equal after the one rounding), in the
+    [Cout/32][Cin][4][32][4] layout."""
+    g = torch.Generator().manual_seed(5)
+    for co, ci in ((64, 8), (128, 24), (256, 256)):
+        w = torch.randn(co, ci, 3, 3, generator=g)
+        G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+        U = torch.einsum("ia,ocab,jb->ocij", G, w.double(), G)
+        ref = U.view(co // 32, 32, ci, 4, 4).permute(0, 2, 3, 1, 4)
+        got = ops.pack_winograd_weight(w.cuda()).cpu()
+        assert tuple(got.shape) == (co // 32, ci, 4, 32, 4)
+        # the kernel evaluates the same sums in double in a fixed order; a double rounding difference of one fp32 ulp is allowed
+        assert (got.double() - ref).abs().max().item() <= 1.2e-7 * ref.abs().max().item()
+        assert torch.equal(got[:, :, 0, :, 0], w[:, :, 0, 0].view(co // 32, 32, ci).permute(0, 2, 1))   # corner taps pass through
+
+
 @pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
 @pytest.mark.parametrize("cfg,split_k", [(-1, 0), (0, 1), (1, 2), (2, 1), (3, 3), (4, 1), (5, 2), (6, 0), (7, 1)])
 def test_conv2d_winograd(ops, case, cfg, split_k):
