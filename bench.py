@@ -374,7 +374,10 @@ def main():
                              "note": "fused kernel never materialises the PxP affinity; compulsory bytes "
                                      "10.76 MB/frame make it MFMA-bound, not HBM-bound (SURVEY.md 8d)"},
                 "whole_path": {"achieved": round(PATH_FLOPS * fps / n_gpus / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(PATH_FLOPS * fps / n_gpus / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}}
+                               "unit": "TFLOP/s", "frac": round(PATH_FLOPS * fps / n_gpus / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                               "flop_count": "algorithmic FLOPs of the path with direct convolutions (348.4 GFLOP per 216x384 "
+                                             "frame, SURVEY.md 8d) x frames/s: an EFFECTIVE rate - the Winograd layers execute "
+                                             "2.25x fewer multiplications, so it may exceed the matrix peak"}}
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

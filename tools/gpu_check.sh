@@ -40,5 +40,5 @@ if [[ $what == pmc || $what == all2 ]]; then
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc2 -o p -- python tools/prof_kernels.py > gpurun_out/pmc2.log 2>&1; echo "pmc2 rc=$?"
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc3 -o p -- python tools/prof_kernels.py > gpurun_out/pmc3.log 2>&1; echo "pmc3 rc=$?"
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU --output-format csv -d gpurun_out/pmc4 -o p -- python tools/prof_kernels.py > gpurun_out/pmc4.log 2>&1; echo "pmc4 rc=$?"
-  ls gpurun_out/pmc*/ ; tail -3 gpurun_out/pmc1.log gpurun_out/pmc4.log
+  ls gpurun_out/pmc*/ ; tail -n 3 gpurun_out/pmc1.log; tail -n 3 gpurun_out/pmc4.log
 fi
