@@ -211,6 +211,8 @@ def main():
     ap.add_argument("--hw", default="216x384",
                     help="frame size HxW; the default is BASELINE configs[1] (the metric's configuration), "
                          "432x768 is configs[3] (information only: no CPU baseline, traffic not re-measured)")
+    ap.add_argument("--front-batch", type=int, default=1,
+                    help="frames per front-end batch of the clip driver (bit-identical to 1: the library plans per image)")
     ap.add_argument("--lookahead", type=int, default=2,
                     help="frames whose front end runs ahead on side HIP streams (0 = per-frame calls on one stream)")
     ap.add_argument("--no-autotune", action="store_true", help="use the static tile cost model instead of first-use timing")
@@ -293,7 +295,7 @@ def main():
     if args.lookahead > 0:
         # second untimed pass over the warm-up frames through the clip driver: the side streams' memory
         # pools (and nothing else) are still cold after the per-frame pass above
-        cc.clip(frames[:Wm], lookahead=args.lookahead)
+        cc.clip(frames[:Wm], lookahead=args.lookahead, front_batch=args.front_batch)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -302,7 +304,7 @@ def main():
     if args.lookahead > 0:
         # the clip driver: front end (VGG19 + WarpNet + correlation) of frames t+1.. on side HIP streams while
         # this stream runs the ColorVidNet recurrence; bit-identical to the per-frame loop below
-        cc.clip(frames[Wm:Wm + K], last=last, lookahead=args.lookahead)
+        cc.clip(frames[Wm:Wm + K], last=last, lookahead=args.lookahead, front_batch=args.front_batch)
         last_timed = cc.last_lab
     else:
         last_timed = last
@@ -406,7 +408,8 @@ def main():
                        "autotuned on first use during warm-up (cf. cudnn.benchmark=True, test.py:140)",
                        "frames_per_gpu": K, "parallelism": f"frame-chunks x{n_gpus}",
                        "clip_driver": "per-frame calls, one stream" if args.lookahead <= 0 else
-                       f"ClipColorizer.clip: front end of the next {args.lookahead} frames on side HIP streams, "
+                       f"ClipColorizer.clip: front end of the next {args.lookahead} frames on side HIP streams, " +
+                       (f"{args.front_batch} frames per set of front-end launches (planned per image), " if args.front_batch > 1 else "") +
                        "ColorVidNet recurrence on the main stream (bit-identical to per-frame calls)",
                        "per_frame_api_frames_per_s": None if seq_fps is None else round(seq_fps, 3)},
             "roofline": roof,

@@ -3,6 +3,8 @@
 // conv_k3d2.hip, conv_k1.hip and conv_gen.hip.
 #include "conv_kernel.h"
 #include "conv_sk_kernel.h"
+#include <algorithm>
+
 #include "conv_wino_kernel.h"
 
 static int virt_dim(int S, int up, int sub) {
@@ -89,12 +91,17 @@ static long long* g_conv_dbg_buf = nullptr;
 extern "C" void dvc_debug_conv_trace(long long* buf) { g_conv_dbg_buf = buf; }   // diagnostics (dvc_hip.h, last section)
 extern "C" void dvc_debug_conv_variant(int v) { g_conv_dbg = v; }
 
-extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_packed,
-                          const float* bias, const float* in_scale, const float* in_shift,
-                          const float* in_slope_ptr, const float* act_slope_ptr,
-                          const float* residual, float* y, void* workspace, size_t workspace_bytes,
-                          dvcStream stream) {
+// One launch (plus its reduce / fixup) for the d->N images at x / y.  The PLAN — tile configuration, split over input
+// channels, stream-K ranges — is always the single-image plan: an image's result never depends on what else is in the
+// batch, and a batch of N is bit-identical to N single-image calls (the clip driver batches look-ahead front ends on that).
+// `*group` (out): images this call covered (the split-K workspace may hold fewer than d->N at the single-image split).
+static int conv2d_images(const DvcConvDesc* d, const float* x, const float* w_packed,
+                         const float* bias, const float* in_scale, const float* in_shift,
+                         const float* in_slope_ptr, const float* act_slope_ptr,
+                         const float* residual, float* y, void* workspace, size_t workspace_bytes,
+                         dvcStream stream, int* group) {
     DVC_REQUIRE(d && x && w_packed && y, "dvc_conv2d: null argument");
+    *group = d->N;
     DVC_REQUIRE(d->ksize == 1 || d->ksize == 3, "dvc_conv2d: ksize must be 1 or 3 (got %d)", d->ksize);
     DVC_REQUIRE(d->stride == 1 || d->stride == 2, "dvc_conv2d: stride must be 1 or 2");
     DVC_REQUIRE(d->dil == 1 || d->dil == 2, "dvc_conv2d: dilation must be 1 or 2");
@@ -182,7 +189,7 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
         sk.px_tiles = sk.tiles_x * cdiv(OH, ph);
         sk.co_blocks = d->Cout / mt;
         sk.NC = d->Cin / ck;
-        const long tiles = (long)d->N * sk.co_blocks * sk.px_tiles;
+        const long tiles = (long)sk.co_blocks * sk.px_tiles;       // of ONE image: the unit ranges are the single-image ones
         sk.U = tiles * sk.NC;
         DVC_REQUIRE(tiles < (1L << 30), "dvc_conv2d: too many tiles");
         int per_cu = sk_per_cu > 0 ? sk_per_cu : 2;
@@ -197,10 +204,16 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
         L.fix_grid = dim3((unsigned)tiles, SK_FIX_SPLIT);
         L.need_fixup = !(sk.U % G == 0 && (sk.U / G) % sk.NC == 0);
         hipStream_t st = (hipStream_t)stream;
-        if (d->ksize == 1) conv_sk_launch_k1(cfg, tw, L, st, sk);
-        else if (d->dil == 1) conv_sk_launch_k3d1(cfg, tw, L, st, sk);
-        else conv_sk_launch_k3d2(cfg, tw, L, st, sk);
-        DVC_CHECK_LAUNCH("dvc_conv2d(stream-K)");
+        sk.k.N = 1;
+        for (int n = 0; n < d->N; ++n) {        // one launch per image (the slots are reused: same stream)
+            sk.k.x = x + (long)n * a.x_bs;
+            sk.k.y = y + (long)n * a.y_bs;
+            sk.k.res = residual ? residual + (long)n * a.res_bs : nullptr;
+            if (d->ksize == 1) conv_sk_launch_k1(cfg, tw, L, st, sk);
+            else if (d->dil == 1) conv_sk_launch_k3d1(cfg, tw, L, st, sk);
+            else conv_sk_launch_k3d2(cfg, tw, L, st, sk);
+            DVC_CHECK_LAUNCH("dvc_conv2d(stream-K)");
+        }
         return 0;
     }
     if (cfg >= 16) {  // 16 + tile configuration: force register staging (autotuner / A-B measurements)
@@ -224,7 +237,7 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
             const ConvCfg& c = kConvCfgs[i];
             int mt = 32 * c.wm * c.rm, ph = c.wn * c.rn * rpt;
             if (d->Cout < mt && i != 1 && i != 3) continue;  // don't waste half the M tile
-            double waves = 4.0 * cdiv(OW, tw) * cdiv(OH, ph) * cdiv(d->Cout, mt) * d->N;
+            double waves = 4.0 * cdiv(OW, tw) * cdiv(OH, ph) * cdiv(d->Cout, mt);     // of one image
             double rounds = waves / 1024.0;
             double p = (i == 4 && rounds <= 1.0) ? 1.10 : pen[i];
             double cost = c.rm * c.rn * (rounds < 1.0 ? 1.0 : rounds) * p;
@@ -248,20 +261,26 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     DVC_REQUIRE(lds <= 160 * 1024, "dvc_conv2d: LDS tile too large (%zu bytes)", lds);
     // split-K over input-channel chunks when the layer cannot put ~2 waves on every SIMD by itself
     const int nchunks = cdiv(d->Cin, ck);
-    const long waves = 4L * cdiv(OW, tw) * cdiv(OH, ph) * cdiv(d->Cout, mt) * d->N;
+    const long waves = 4L * cdiv(OW, tw) * cdiv(OH, ph) * cdiv(d->Cout, mt);      // of one image
     int S = 1;
     if (workspace && d->split_k != 1 && waves < 1536 && nchunks >= 4) {
         S = d->split_k > 1 ? d->split_k : (int)((2048 + waves - 1) / waves);
         if (d->split_k <= 1 && S > 4) S = 4;   // the static heuristic stays conservative; deeper splits are for the tuner
         if (S > 8) S = 8;
         if (S > nchunks / 2) S = nchunks / 2;
-        while (S > 1 && (size_t)S * d->N * d->Cout * OH * OW * sizeof(float) > workspace_bytes) --S;
+        while (S > 1 && (size_t)S * d->Cout * OH * OW * sizeof(float) > workspace_bytes) --S;
     }
     a.chunks_per_split = cdiv(nchunks, S);
     S = cdiv(nchunks, a.chunks_per_split);
     a.split = S;
+    if (S > 1) {     // as many images per launch as the workspace holds partial sums for
+        const size_t per_image = (size_t)S * d->Cout * OH * OW * sizeof(float);
+        if ((size_t)d->N * per_image > workspace_bytes) *group = (int)(workspace_bytes / per_image);
+        a.N = *group;
+    }
+    const int NB = a.N;
     a.part = reinterpret_cast<float*>(workspace);
-    dim3 grid(cdiv(OW, tw) * cdiv(OH, ph), cdiv(d->Cout, mt), d->N * S);
+    dim3 grid(cdiv(OW, tw) * cdiv(OH, ph), cdiv(d->Cout, mt), NB * S);
     hipStream_t s = (hipStream_t)stream;
     // "plain" layers stage through LDS-DMA (see conv_kernel.h)
     const bool dma = allow_dma && !gen && !in_scale && !d->in_prelu && d->Cin % ck == 0 && d->Cout % mt == 0;
@@ -276,16 +295,44 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     DVC_CHECK_LAUNCH("dvc_conv2d");
     if (S > 1) {
         const long OHW = (long)OH * OW, per_img = (long)d->Cout * OHW;
-        const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)d->N * per_img) % 4 == 0);
+        const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)NB * per_img) % 4 == 0);
         if (v4)
-            hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)((per_img / 4 + 255) / 256), d->N), dim3(256), 0, s,
-                               a.part, S, (long)d->N * per_img, d->Cout, OHW, bias, residual, a.res_bs, d->act,
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)((per_img / 4 + 255) / 256), NB), dim3(256), 0, s,
+                               a.part, S, (long)NB * per_img, d->Cout, OHW, bias, residual, a.res_bs, d->act,
                                d->act_slope, act_slope_ptr, y, a.y_bs);
         else
-            hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3((unsigned)((per_img + 255) / 256), d->N), dim3(256), 0, s,
-                               a.part, S, (long)d->N * per_img, d->Cout, OHW, bias, residual, a.res_bs, d->act,
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3((unsigned)((per_img + 255) / 256), NB), dim3(256), 0, s,
+                               a.part, S, (long)NB * per_img, d->Cout, OHW, bias, residual, a.res_bs, d->act,
                                d->act_slope, act_slope_ptr, y, a.y_bs);
         DVC_CHECK_LAUNCH("dvc_conv2d(split-K reduce)");
+    }
+    return 0;
+}
+
+extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_packed,
+                          const float* bias, const float* in_scale, const float* in_shift,
+                          const float* in_slope_ptr, const float* act_slope_ptr,
+                          const float* residual, float* y, void* workspace, size_t workspace_bytes,
+                          dvcStream stream) {
+    DVC_REQUIRE(d, "dvc_conv2d: null descriptor");
+    DvcConvDesc g = *d;
+    int32_t OH = 0, OW = 0;
+    dvc_conv2d_out_hw(d, &OH, &OW);
+    const long x_bs = d->x_batch_stride ? d->x_batch_stride : (long)d->Cin * d->H * d->W;
+    const long y_bs = d->y_batch_stride ? d->y_batch_stride : (long)d->Cout * OH * OW;
+    const long r_bs = d->res_batch_stride ? d->res_batch_stride : (long)d->Cout * OH * OW;
+    g.x_batch_stride = x_bs; g.y_batch_stride = y_bs; g.res_batch_stride = r_bs;
+    for (int n0 = 0; n0 < d->N;) {       // (one pass unless the split-K workspace is smaller than the batch needs)
+        g.N = d->N - n0;
+        int done = 0;
+        const int rc = conv2d_images(&g, x ? x + (long)n0 * x_bs : x, w_packed, bias,
+                                     in_scale ? in_scale + (long)n0 * d->Cin : nullptr,
+                                     in_shift ? in_shift + (long)n0 * d->Cin : nullptr, in_slope_ptr, act_slope_ptr,
+                                     residual ? residual + (long)n0 * r_bs : nullptr, y ? y + (long)n0 * y_bs : y, workspace,
+                                     workspace_bytes, stream, &done);
+        if (rc != 0) return rc;
+        DVC_REQUIRE(done > 0, "dvc_conv2d: split-K workspace too small for one image");
+        n0 += done;
     }
     return 0;
 }
@@ -383,11 +430,12 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
         for (int ti = 0; ti < 4; ++ti) {
             const int tr = kTR[ti];
             if (shape_cfg >= 0 && shape_cfg % 4 != ti) continue;
-            const long wgs = (long)s.ss * s.ss * cdiv(TY, tr * wn) * cdiv(TX, 32 / tr) * (d->Cout / (32 * wm)) * d->N;
+            // (workgroups of ONE image: the plan never depends on the batch size, see conv2d_images)
+            const long wgs = (long)s.ss * s.ss * cdiv(TY, tr * wn) * cdiv(TX, 32 / tr) * (d->Cout / (32 * wm));
             for (int S = 1; S <= 8; ++S) {
                 if (d->split_k > 0 && S != d->split_k) continue;
                 if (S > 1 && (!workspace || S > nch / 2 ||
-                              (size_t)S * d->N * d->Cout * OH * OW * sizeof(float) > workspace_bytes)) continue;
+                              (size_t)S * d->Cout * OH * OW * sizeof(float) > workspace_bytes)) continue;
                 const int cps = cdiv(nch, S);
                 if (cdiv(nch, cps) != S) continue;
                 const double rounds = (double)cdivl(wgs * S, ncu);
@@ -407,25 +455,37 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
     a.part = reinterpret_cast<float*>(workspace);
     s.gx = s.ss * s.ss * s.blk_y * s.blk_x;
     s.gy = d->Cout / (32 * wm);
-    s.gz = d->N * a.split;
-    DVC_REQUIRE((long)s.gx * s.gy * s.gz < (1L << 31), "dvc_conv2d_winograd: grid too large");
-    dim3 grid((unsigned)(s.gx * s.gy * s.gz));      // 1-D: the kernel maps it XCD-aware onto (gx, gy, gz)
     hipStream_t st = (hipStream_t)stream;
-    if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
-    else conv_wino_launch_m2(best_tr, grid, st, s);
-    DVC_CHECK_LAUNCH("dvc_conv2d_winograd");
-    if (a.split > 1) {
-        const long OHW = (long)OH * OW, per_img = (long)d->Cout * OHW;
-        const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)d->N * per_img) % 4 == 0);
-        if (v4)
-            hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)((per_img / 4 + 255) / 256), d->N), dim3(256), 0, st,
-                               a.part, a.split, (long)d->N * per_img, d->Cout, OHW, bias, residual, a.res_bs, d->act,
-                               d->act_slope, act_slope_ptr, y, a.y_bs);
-        else
-            hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3((unsigned)((per_img + 255) / 256), d->N), dim3(256), 0, st,
-                               a.part, a.split, (long)d->N * per_img, d->Cout, OHW, bias, residual, a.res_bs, d->act,
-                               d->act_slope, act_slope_ptr, y, a.y_bs);
-        DVC_CHECK_LAUNCH("dvc_conv2d_winograd(split-K reduce)");
+    const long OHW = (long)OH * OW, per_img = (long)d->Cout * OHW;
+    // images per launch: all of them, unless the workspace holds the partial outputs of fewer at this (single-image) split
+    int group = d->N;
+    if (a.split > 1 && (size_t)d->N * a.split * per_img * sizeof(float) > workspace_bytes)
+        group = (int)(workspace_bytes / ((size_t)a.split * per_img * sizeof(float)));
+    DVC_REQUIRE(group > 0, "dvc_conv2d_winograd: split-K workspace too small for one image");
+    for (int n0 = 0; n0 < d->N; n0 += group) {
+        const int NB = std::min(group, d->N - n0);
+        a.N = NB;
+        a.x = x + (long)n0 * a.x_bs;
+        a.y = y + (long)n0 * a.y_bs;
+        a.res = residual ? residual + (long)n0 * a.res_bs : nullptr;
+        s.gz = NB * a.split;
+        DVC_REQUIRE((long)s.gx * s.gy * s.gz < (1L << 31), "dvc_conv2d_winograd: grid too large");
+        dim3 grid((unsigned)(s.gx * s.gy * s.gz));      // 1-D: the kernel maps it XCD-aware onto (gx, gy, gz)
+        if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
+        else conv_wino_launch_m2(best_tr, grid, st, s);
+        DVC_CHECK_LAUNCH("dvc_conv2d_winograd");
+        if (a.split > 1) {
+            const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)NB * per_img) % 4 == 0);
+            if (v4)
+                hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)((per_img / 4 + 255) / 256), NB), dim3(256), 0, st,
+                                   a.part, a.split, (long)NB * per_img, d->Cout, OHW, bias, a.res, a.res_bs, d->act,
+                                   d->act_slope, act_slope_ptr, a.y, a.y_bs);
+            else
+                hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3((unsigned)((per_img + 255) / 256), NB), dim3(256), 0, st,
+                                   a.part, a.split, (long)NB * per_img, d->Cout, OHW, bias, a.res, a.res_bs, d->act,
+                                   d->act_slope, act_slope_ptr, a.y, a.y_bs);
+            DVC_CHECK_LAUNCH("dvc_conv2d_winograd(split-K reduce)");
+        }
     }
     return 0;
 }

@@ -608,6 +608,20 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
     if (y_up || sim_up)
         DVC_REQUIRE(((reinterpret_cast<uintptr_t>(y_up) | reinterpret_cast<uintptr_t>(sim_up)) & 15) == 0,
                     "dvc_corr_fwd: upsampled outputs must be 16-byte aligned");
+    // One image per set of launches, each with the single-image decomposition: an image's result does not depend on the
+    // batch it came in (the stream-K unit ranges, hence the order in which partial softmax states are merged, would
+    // otherwise change with B).  The launches are 0.13 ms each; nothing is lost.
+    if (B > 1) {
+        const long PC = (long)CORR_C * P, P16 = 16L * P;
+        for (int b = 0; b < B; ++b) {
+            const int rc = dvc_corr_fwd(theta + b * PC, phi + b * PC, blab + (long)b * 3 * P, temperature, wta_scale, 1, C, h, w,
+                                        y_small ? y_small + (long)b * 3 * P : nullptr, sim_small ? sim_small + (long)b * P : nullptr,
+                                        y_up ? y_up + b * 3 * P16 : nullptr, sim_up ? sim_up + b * P16 : nullptr,
+                                        argmax ? argmax + (long)b * P : nullptr, workspace, workspace_bytes, stream);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
     CorrArgs a;
     a.dbg = g_corr_dbg; a.dbg_tiles = g_corr_dbg_tiles; a.dbg_variant = g_corr_dbg_variant;
     a.theta = theta; a.phi = phi; a.blab = blab;

@@ -124,7 +124,7 @@ class ClipColorizer:
                                        temperature=self.temperature, exemplar_cache=self.ex_cache)
         return ab, nl
 
-    def clip(self, frames_lab, frame_propagate=False, last=None, lookahead=2, on_frame=None):
+    def clip(self, frames_lab, frame_propagate=False, last=None, lookahead=2, on_frame=None, front_batch=1):
         """Recurrence of test.py:68-96; returns the list of ab predictions.
 
         Only ColorVidNet(t) consumes frame t-1's prediction (test.py:96 -> FrameColor.py:63-64); the
@@ -133,6 +133,12 @@ class ClipColorizer:
         streams while the current stream runs the ColorVidNet chain, so their workgroups fill the CUs
         the other stream's layer leaves idle (few-tile layers, tail rounds).  Same kernels, same
         per-frame arithmetic and order: the predictions are bit-identical to the sequential loop.
+        `front_batch` frames share one set of front-end launches (batch dimension): the library plans every
+        launch per image (csrc/conv_mfma.hip: conv2d_images), so a batch of N is bit-identical to N single-image
+        calls while the per-launch costs are paid once per batch.  (Measured on the MI355X: the front end of four frames
+        takes 24 % less time as one batch on an otherwise idle GPU, but inside this driver the other stream already fills
+        those gaps — 384-388 frames/s for every batch size — so the default stays 1; the option matters where the host's
+        launch rate is the limit.)
         `last` (optional) continues the recurrence from an earlier call.  `on_frame(t, IA_lab, ab)`
         (optional) is called right after frame t's launches have been issued, with the recurrence stream
         current — the hook `clip_rgb` hangs the per-frame tail on."""
@@ -167,35 +173,42 @@ class ClipColorizer:
         for s in side + [cur]:
             s.wait_stream(caller)       # inputs, weights and the exemplar cache were produced on the caller's stream
         fronts = {}
+        T = len(frames_lab)
+        nb = max(1, int(front_batch))
+        if isinstance(self.ex_cache, tuple) and isinstance(self.ex_cache[0], tuple):
+            nb = 1                      # (the bf16 candidate-filter correlation takes one image per call)
+        batches = [list(range(i, min(i + nb, T))) for i in range(0, T, nb)]
 
-        def launch_front(t):
-            s = side[t % lookahead]
+        def launch_front(bi):
+            s = side[bi % lookahead]
             with torch.cuda.stream(s):
-                IA_lab = frames_lab[t].detach().contiguous().float()
+                fr = [frames_lab[t].detach().contiguous().float() for t in batches[bi]]
+                IA_lab = fr[0] if len(fr) == 1 else torch.cat(fr, dim=0)
                 warped, sim, _ = warp_color(IA_lab[:, 0:1], self.IB_lab, self.features_B, self.vgg, self.warp,
                                             self.col, 0, temperature=self.temperature,
                                             exemplar_cache=self.ex_cache)
                 ev = torch.cuda.Event()
                 ev.record(s)
-            fronts[t] = (IA_lab, warped, sim, ev)
+            fronts[bi] = (IA_lab, warped, sim, ev)
 
-        T = len(frames_lab)
-        for t in range(min(lookahead, T)):
-            launch_front(t)
-        for t in range(T):
-            IA_lab, warped, sim, ev = fronts.pop(t)
+        for bi in range(min(lookahead, len(batches))):
+            launch_front(bi)
+        for bi, members in enumerate(batches):
+            IA_b, warped_b, sim_b, ev = fronts.pop(bi)
             cur.wait_event(ev)
-            for x in (IA_lab, warped, sim):
+            for x in (IA_b, warped_b, sim_b):
                 x.record_stream(cur)    # allocated on a side stream, consumed here
-            with torch.cuda.stream(cur):
-                color_input = ops.pack_color_input(IA_lab, warped, sim, last.detach().contiguous().float())
-                ab = self.col(color_input)
-                last = torch.cat((IA_lab[:, 0:1], ab), dim=1)
-                if on_frame is not None:
-                    on_frame(t, IA_lab, ab)
-            outs.append(ab)
-            if t + lookahead < T:       # (issued after the critical-path launches of frame t)
-                launch_front(t + lookahead)
+            for j, t in enumerate(members):
+                IA_lab, warped, sim = IA_b[j:j + 1], warped_b[j:j + 1], sim_b[j:j + 1]
+                with torch.cuda.stream(cur):
+                    color_input = ops.pack_color_input(IA_lab, warped, sim, last.detach().contiguous().float())
+                    ab = self.col(color_input)
+                    last = torch.cat((IA_lab[:, 0:1], ab), dim=1)
+                    if on_frame is not None:
+                        on_frame(t, IA_lab, ab)
+                outs.append(ab)
+                if j == 0 and bi + lookahead < len(batches):   # (issued after the critical-path launches of the frame)
+                    launch_front(bi + lookahead)
         caller.wait_stream(cur)
         for x in outs + [last]:
             x.record_stream(caller)     # allocated on the recurrence stream, handed to the caller's stream

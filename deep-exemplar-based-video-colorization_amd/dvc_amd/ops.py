@@ -130,11 +130,15 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
     if residual is not None:
         assert tuple(residual.shape) == (N, Cout, OH, OW), (residual.shape, (N, Cout, OH, OW))
     if _autotune and cfg == -1 and split_k == 0:
-        key = (N, Cin, H, W, Cout, ksize, stride, dil, pad, pad_mode, in_up, in_sub, in_scale is not None,
+        # (no N in the key and a single-image descriptor for the timing: the library plans per image, so that a batch is
+        # bit-identical to single-image calls — the tuned choice must not depend on the batch size either)
+        key = (Cin, H, W, Cout, ksize, stride, dil, pad, pad_mode, in_up, in_sub, in_scale is not None,
                in_slope_t is not None, residual is not None, act, x.device.index)
         best = _tuned.get(key)
         if best is None:
-            best = _tune_conv(lib, d, (x, w_packed, bias, in_scale, in_shift, in_slope_t, act_slope_t, residual, out))
+            d1 = DvcConvDesc.from_buffer_copy(d)
+            d1.N = 1
+            best = _tune_conv(lib, d1, (x, w_packed, bias, in_scale, in_shift, in_slope_t, act_slope_t, residual, out))
             _tuned[key] = best
             _save_tuned()
         d.cfg, d.split_k = best
@@ -229,7 +233,8 @@ def winograd_selected(N, Cin, H, W, Cout, *, ksize=3, stride=1, dil=1, pad=1, in
 def _wino_rule(N, Cin, Cout, OH, OW, dil):
     # measured on the MI355X (profiles/r02_conv_wino_probe.txt): Winograd wins wherever the layer has enough 2x2 tiles
     # to fill the chip after the split over input channels; the 13x24 VGG block-5 layers stay on the direct engine
-    return N * OH * OW >= 27 * 48
+    # (per image, never a function of the batch size: a batch must run the kernels its images would run alone)
+    return OH * OW >= 27 * 48
 
 
 def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1, act=ACT_NONE, act_slope=0.0,
@@ -473,7 +478,9 @@ def corr_fwd(theta, phi, blab, temperature, h, w, wta_scale=1.0, want_small=Fals
     for t, nm in ((theta, "theta"), (phi, "phi"), (blab, "blab")):
         _need(t, nm)
     B, C, P = theta.shape
-    assert P == h * w and tuple(phi.shape) == (B, C, P) and blab.shape[0] == B and blab[0].numel() == 3 * P
+    shared = B > 1 and phi.shape[0] == 1 and blab.shape[0] == 1     # one exemplar for a batch of frames (clip driver)
+    assert P == h * w and tuple(phi.shape[1:]) == (C, P) and blab[0].numel() == 3 * P
+    assert shared or (phi.shape[0] == B and blab.shape[0] == B), (theta.shape, phi.shape, blab.shape)
     if not (temperature > 0):
         raise ValueError("temperature must be > 0")
     dev = theta.device
@@ -489,11 +496,20 @@ def corr_fwd(theta, phi, blab, temperature, h, w, wta_scale=1.0, want_small=Fals
         amax = torch.empty((B, P), device=dev, dtype=torch.int32)
     nbytes = lib.dvc_corr_workspace_bytes(B, P)
     ws = _workspace(dev, nbytes)
-    rc = lib.dvc_corr_fwd(_p(theta), _p(phi), _p(blab), float(temperature), float(wta_scale), B, C, h, w,
-                          _p(y_small), _p(sim_small), _p(y_up), _p(sim_up),
-                          None if amax is None else ctypes.c_void_p(amax.data_ptr()),
-                          ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
-    _lib.check(rc, "dvc_corr_fwd")
+
+    def call(th, nb, sl):
+        o = [None if t is None else t[sl] for t in (y_small, sim_small, y_up, sim_up)]
+        rc = lib.dvc_corr_fwd(_p(th), _p(phi), _p(blab), float(temperature), float(wta_scale), nb, C, h, w,
+                              _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]),
+                              None if amax is None else ctypes.c_void_p(amax[sl].data_ptr()),
+                              ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+        _lib.check(rc, "dvc_corr_fwd")
+
+    if shared:      # the library runs one image per set of launches anyway (results independent of the batch size)
+        for b in range(B):
+            call(theta[b:b + 1], 1, slice(b, b + 1))
+    else:
+        call(theta, B, slice(0, B))
     out.update(y_up=y_up, sim_up=sim_up, y_small=y_small, sim_small=sim_small, argmax=amax)
     return out
 
