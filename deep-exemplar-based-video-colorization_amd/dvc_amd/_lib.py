@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvc_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -44,6 +44,14 @@ SIGNATURES = {
                                       c_i64, c_i64, c_i64, _VP, _VP]),
     "dvc_instnorm_apply": (ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i32, c_i32, c_i32,
                                           c_i32, c_i32, c_i64, c_i64, c_i64, _VP, _VP, _VP, _VP, c_i32, _VP, _VP]),
+    "dvc_cx_prepare": (ctypes.c_int, [_VP, _VP, c_i32, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP, _VP]),
+    "dvc_cx_rows": (ctypes.c_int, [_VP, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "dvc_cx_colmax": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP]),
+    "dvc_cx_finish": (ctypes.c_int, [_VP, c_i32, _VP, _VP, _VP]),
+    "dvc_cx_rows_tq": (ctypes.c_int, [_VP, _VP, _VP, _VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP]),
+    "dvc_cx_ds": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,
+                                 c_i32, ctypes.c_float, _VP, _VP, _VP]),
+    "dvc_cx_normalize_bwd": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP]),
     "dvc_maxpool2x2": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),
     "dvc_avgpool2x2": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),
     "dvc_avgpool4x4": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),

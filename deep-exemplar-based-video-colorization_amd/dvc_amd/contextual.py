@@ -1,0 +1,157 @@
+"""Contextual loss on the HIP kernels — the reference's other N x N cosine-affinity consumer.
+
+`ContextualLoss_forward` / `ContextualLoss` of /root/reference/models/ContextualLoss.py:29-126, as train.py:649-668 calls
+them: `contextual_forward_loss(predict_relu5_1, B_relu5_1.detach())` on VGG features of the prediction (gradient wanted)
+and of the exemplar (detached).  Same constructor / forward signatures, same per-sample return value [B].
+
+    mu = mean_j Y;  Xn, Yn = (. - mu) / (||.||_C + eps)      dvc_cx_prepare
+    S  = Xn^T Yn  in blocks of R rows                         1x1-convolution engine (ops.conv2d)
+    a_i, j*_i, l_i, r_i = max_j A_ij, E_i                     dvc_cx_rows          (A = softmax_j((1 - d / a_i) / h), d = 1 - S)
+    column maxima of A over the rows (ContextualLoss only)    dvc_cx_colmax
+    loss = -log mean(.)                                       dvc_cx_finish
+backward (w.r.t. X; Y is data, as in train.py): S block recomputed, dS by dvc_cx_ds (+ dvc_cx_rows_tq), d Xn = Yn dS^T on
+the engine, then dvc_cx_normalize_bwd.  Nothing N x N outlives a row block.  Parity: tests/test_gpu_contextual.py against
+float64 autograd through the oracle restatement (oracle/contextual_oracle.py, pinned to the reference module).
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .ops import EPS64, _p, _stream
+
+ROW_BLOCK = 512
+
+
+def _ip(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class _ContextualCX(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, Y, h, centering, mode):
+        lib = _lib.load()
+        X = X.detach().contiguous().float()
+        Y = Y.detach().contiguous().float()
+        for t, nm in ((X, "X_features"), (Y, "Y_features")):
+            ops._need(t, nm)
+        B, C = X.shape[0], X.shape[1]
+        Nx, Ny = X[0, 0].numel(), Y[0, 0].numel()
+        assert Y.shape[0] == B and Y.shape[1] == C, (X.shape, Y.shape)
+        dev = X.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        Xn, Yn = torch.empty((B, C, Nx), **f32), torch.empty((B, C, Ny), **f32)
+        meanY, normX = torch.empty(B * C, **f32), torch.empty((B, Nx), **f32)
+        st = _stream()
+        _lib.check(lib.dvc_cx_prepare(_p(Y), None, int(centering), B, C, Ny, float(EPS64), _p(meanY), None, _p(Yn), st), "dvc_cx_prepare")
+        _lib.check(lib.dvc_cx_prepare(_p(X), _p(meanY), int(centering), B, C, Nx, float(EPS64), None, _p(normX), _p(Xn), st),
+                   "dvc_cx_prepare")
+        a, l, r, e = (torch.empty((B, Nx), **f32) for _ in range(4))
+        jstar = torch.empty((B, Nx), device=dev, dtype=torch.int32)
+        cmax = torch.full((B, Ny), -1.0, **f32) if mode == 1 else None
+        cargi = torch.zeros((B, Ny), device=dev, dtype=torch.int32) if mode == 1 else None
+        loss, gscale = torch.empty(B, **f32), torch.empty(B, **f32)
+        R = min(ROW_BLOCK, (Nx + 63) // 64 * 64)
+        hy, wy = (Y.shape[2], Y.shape[3]) if Y.dim() == 4 else (1, Ny)
+        S = torch.empty((1, R, hy, wy), **f32)
+        for b in range(B):
+            y_img = Yn[b].view(1, C, hy, wy)
+            for i0 in range(0, Nx, R):
+                rows = min(R, Nx - i0)
+                _s_block(Xn[b], y_img, i0, rows, R, S)
+                sl = slice(i0, i0 + rows)
+                _lib.check(lib.dvc_cx_rows(_p(S), rows, Ny, float(h), _p(a[b, sl]), _ip(jstar[b, sl]), _p(l[b, sl]), _p(r[b, sl]),
+                                           _p(e[b, sl]), st), "dvc_cx_rows")
+                if mode == 1:
+                    _lib.check(lib.dvc_cx_colmax(_p(S), _p(a[b, sl]), _p(l[b, sl]), rows, Ny, i0, float(h), _p(cmax[b]),
+                                                 _ip(cargi[b]), st), "dvc_cx_colmax")
+            v, n = (r[b], Nx) if mode == 0 else (cmax[b], Ny)
+            _lib.check(lib.dvc_cx_finish(_p(v), n, _p(loss[b:b + 1]), _p(gscale[b:b + 1]), st), "dvc_cx_finish")
+        saved = [Xn, Yn, normX, a, l, r, e, jstar, gscale] + ([cargi] if mode == 1 else [])
+        ctx.save_for_backward(*saved)
+        ctx.meta = (float(h), int(mode), tuple(X.shape), (hy, wy))
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        h, mode, xshape, (hy, wy) = ctx.meta
+        saved = ctx.saved_tensors
+        Xn, Yn, normX, a, l, r, e, jstar, gscale = saved[:9]
+        cargi = saved[9] if mode == 1 else None
+        B, C, Nx = Xn.shape
+        Ny = Yn.shape[2]
+        dev = Xn.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        st = _stream()
+        gout = gout.detach().float().cpu().tolist()            # B scalars (the loss is per sample)
+        R = min(ROW_BLOCK, (Nx + 63) // 64 * 64)
+        S = torch.empty((1, R, hy, wy), **f32)
+        dST = torch.empty((1, Ny, R // 32, 32), **f32)                       # [Ny][R] as an image of R "pixels"
+        tt, qq = (torch.empty(R, **f32), torch.empty(R, **f32)) if mode == 1 else (None, None)
+        dXn = torch.empty_like(Xn)
+        for b in range(B):
+            y_img = Yn[b].view(1, C, hy, wy)
+            y_t = Yn[b].t().contiguous().view(Ny, 1, C)                      # K-major weights of d Xn = Yn dS^T
+            for i0 in range(0, Nx, R):
+                rows = min(R, Nx - i0)
+                _s_block(Xn[b], y_img, i0, rows, R, S)
+                sl = slice(i0, i0 + rows)
+                if mode == 1:
+                    _lib.check(lib.dvc_cx_rows_tq(_p(S), _p(a[b, sl]), _p(l[b, sl]), _ip(cargi[b]), rows, Ny, i0, h, _p(tt), _p(qq),
+                                                  st), "dvc_cx_rows_tq")
+                _lib.check(lib.dvc_cx_ds(_p(S), _p(a[b, sl]), _p(l[b, sl]), _p(r[b, sl]), _p(e[b, sl]), _ip(jstar[b, sl]),
+                                         None if cargi is None else _ip(cargi[b]), _p(tt), _p(qq), _p(gscale[b:b + 1]),
+                                         float(gout[b]), mode, rows, Ny, i0, R, h, None, _p(dST), st), "dvc_cx_ds")
+                dxb = ops.conv2d(dST, y_t, None, ksize=1, pad=0)              # [1, C, R/32, 32]
+                dXn[b][:, i0:i0 + rows] = dxb.view(C, R)[:, :rows]
+        dX = torch.empty_like(Xn)
+        _lib.check(lib.dvc_cx_normalize_bwd(_p(Xn), _p(normX), _p(dXn), B, C, Nx, float(EPS64), _p(dX), st), "dvc_cx_normalize_bwd")
+        return dX.view(xshape), None, None, None, None
+
+
+def _s_block(Xn_b, y_img, i0, rows, R, S):
+    """S[i, :] = sum_c Xn[c, i0 + i] Yn[c, :] for a block of R rows (zero rows beyond `rows`), on the 1x1-conv engine."""
+    C = Xn_b.shape[0]
+    blk = torch.zeros((C, R), device=Xn_b.device, dtype=torch.float32)
+    blk[:, :rows] = Xn_b[:, i0:i0 + rows]
+    ops.conv2d(y_img, blk.view(C, 1, R), None, ksize=1, pad=0, out=S)
+
+
+def _check(X_features, Y_features):
+    if not (X_features.is_cuda and Y_features.is_cuda):
+        raise RuntimeError("ContextualLoss: inputs must be ROCm device tensors; the MI355X HIP path has no CPU fallback")
+    if Y_features.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError(
+            "ContextualLoss: gradients flow to X_features only (train.py:651-661 passes the exemplar features detached); "
+            "detach Y_features")
+
+
+class ContextualLoss_forward(nn.Module):
+    """
+    input is Al, Bl, channel = 1, range ~ [0, 255]          (docstring of models/ContextualLoss.py:89-91)
+    """
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, X_features, Y_features, h=0.1, feature_centering=True):
+        """X_features & Y_features are feature vectors or feature 2d arrays; h: bandwidth; returns the per-sample loss
+        (models/ContextualLoss.py:97-126: CX = mean over X positions of the row maxima of A)."""
+        _check(X_features, Y_features)
+        return _ContextualCX.apply(X_features, Y_features, float(h), bool(feature_centering), 0)
+
+
+class ContextualLoss(nn.Module):
+    """
+    input is Al, Bl, channel = 1, range ~ [0, 255]          (docstring of models/ContextualLoss.py:30-32)
+    """
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, X_features, Y_features, h=0.1, feature_centering=True):
+        """models/ContextualLoss.py:38-77: CX = mean over Y positions of the column maxima of A."""
+        _check(X_features, Y_features)
+        return _ContextualCX.apply(X_features, Y_features, float(h), bool(feature_centering), 1)

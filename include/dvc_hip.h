@@ -27,7 +27,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 7
+#define DVC_ABI_VERSION 8
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -264,6 +264,42 @@ int dvc_corr_fwd_bf16(const void* theta_bf16_pc, const void* phi_bf16_pc, const 
                       const float* phi_f32_pc, const float* blab, float temperature, int32_t B, int32_t C,
                       int32_t h, int32_t w, float* y_small, float* sim_small, float* y_up, float* sim_up,
                       int32_t* argmax, void* workspace, size_t workspace_bytes, dvcStream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Contextual loss (models/ContextualLoss.py:29-126: `ContextualLoss_forward` :88-126 and `ContextualLoss` :29-77; called by
+ * train.py:649-668 on relu3_1 / relu4_1 / relu5_1 features of the prediction and of the exemplar).  Per image, X = predicted,
+ * Y = exemplar features [C][N]:   mu = mean_j Y;  Xn, Yn = (. - mu) / (||.||_C + eps);  S = Xn^T Yn;  d = 1 - S;
+ * a_i = min_j d_ij + 1e-5;  A = softmax_j((1 - d / a_i) / h);  CX = mean_i max_j A_ij  (_forward)  |  mean_j max_i A_ij;
+ * loss = -log CX.  The GEMMs run as 1x1 convolutions (dvc_conv2d) from the host (dvc_amd/contextual.py) in blocks of rows
+ * of S; these entries are the pieces in between, forward and backward (gradient w.r.t. X; Y is data, as in train.py). */
+/* x [B][C][P] -> out = (x - mean) / (||x - mean||_C + eps).  centre == 0: no mean.  mean_in != NULL: use it ([B*C], e.g. the
+ * exemplar's, ContextualLoss.py:49-51); otherwise the own per-channel mean is computed into mean_out.  norm_out [B][P] (or
+ * NULL) receives ||x - mean||_C (needed by dvc_cx_normalize_bwd). */
+int dvc_cx_prepare(const float* x, const float* mean_in, int32_t centre, int32_t B, int32_t C, int32_t P, float eps,
+                   float* mean_out, float* norm_out, float* out, dvcStream stream);
+/* S [rows][N] (a block of rows of Xn^T Yn) -> per row: a = (1 - max_j S) + 1e-5, jstar = arg max_j S (lowest index on ties),
+ * l = sum_j w, r = max_j A = w_jstar / l, e = sum_j A_ij d_ij, with w = exp((1 - d / a) / h). */
+int dvc_cx_rows(const float* S, int32_t rows, int32_t N, float h, float* a, int32_t* jstar, float* l, float* r, float* e,
+                dvcStream stream);
+/* ContextualLoss only: running column maxima of A over row blocks (cmax initialised below 0, cargi = the winning global row,
+ * row0 = global index of the block's first row). */
+int dvc_cx_colmax(const float* S, const float* a, const float* l, int32_t rows, int32_t N, int32_t row0, float h, float* cmax,
+                  int32_t* cargi, dvcStream stream);
+/* loss = -log(mean(v[0..n))),  gscale = d loss / d v_k = -1 / (n mean(v)) */
+int dvc_cx_finish(const float* v, int32_t n, float* loss, float* gscale, dvcStream stream);
+/* ContextualLoss backward: per row i of the block, t = sum of A_ik over the columns k whose maximum sits in row i
+ * (cargi[k] == row0 + i), q = the same sum weighted by d_ik. */
+int dvc_cx_rows_tq(const float* S, const float* a, const float* l, const int32_t* cargi, int32_t rows, int32_t N, int32_t row0,
+                   float h, float* t, float* q, dvcStream stream);
+/* d loss / d S for a block of rows, row-major (dS, may be NULL) and transposed (dST [N][ld_t], rows >= `rows` zero-filled:
+ * the K-major operand of d Xn = Yn dS^T).  mode 0 = ContextualLoss_forward, 1 = ContextualLoss (needs cargi, t, q).
+ * gscale: device scalar from dvc_cx_finish; gout: the upstream gradient of this image's loss. */
+int dvc_cx_ds(const float* S, const float* a, const float* l, const float* r, const float* e, const int32_t* jstar,
+              const int32_t* cargi, const float* t, const float* q, const float* gscale, float gout, int32_t mode, int32_t rows,
+              int32_t N, int32_t row0, int32_t ld_t, float h, float* dS, float* dST, dvcStream stream);
+/* backward of xn = xc / (||xc|| + eps) per position: dx = dxn / (n + eps) - xn (xn . dxn) / n. */
+int dvc_cx_normalize_bwd(const float* xn, const float* norm, const float* dxn, int32_t B, int32_t C, int32_t P, float eps,
+                         float* dx, dvcStream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of the fused correlation (training-side callers: train.py:402-427 runs frame_colorization, hence
