@@ -85,7 +85,18 @@ def test_reference_import_block_resolves_with_package_in_front():
             raise AssertionError("unknown name resolved")
         # models/ is a namespace package in both trees: the reference's other model files stay reachable
         import importlib.util
-        assert importlib.util.find_spec("models.ContextualLoss").origin == os.path.join(ref, "models", "ContextualLoss.py")
+        assert importlib.util.find_spec("models.GAN_models").origin == os.path.join(ref, "models", "GAN_models.py")
+        assert importlib.util.find_spec("models.spectral_normalization").origin == os.path.join(ref, "models", "spectral_normalization.py")
+        # train.py:22 `from models.ContextualLoss import ContextualLoss, ContextualLoss_forward`: the two HIP-backed losses from
+        # this package, every other name of that file forwarded to the reference's own (loaded unmodified)
+        import dvc_amd.contextual
+        from models.ContextualLoss import ContextualLoss, ContextualLoss_forward
+        assert ContextualLoss is dvc_amd.contextual.ContextualLoss and ContextualLoss_forward is dvc_amd.contextual.ContextualLoss_forward
+        sys.modules["torchvision.transforms"].__dict__.update(Compose=lambda fs: fs, Lambda=lambda f: f,
+                                                              Normalize=lambda mean=None, std=None: None, ToPILImage=lambda: None)
+        from models.ContextualLoss import ContextualLoss_complex, ChamferDistance_loss
+        for cls in (ContextualLoss_complex, ChamferDistance_loss):
+            assert sys.modules[cls.__module__].__file__ == os.path.join(ref, "models", "ContextualLoss.py"), cls
         print("OK")
     ''')
     assert "OK" in _run(code)
