@@ -377,6 +377,71 @@ extern "C" int dvc_winograd_pack_weight(const float* w, int32_t Cout, int32_t Ci
     return 0;
 }
 
+// The plan of a Winograd launch: workgroup shape m, tile-block shape TR x (32/TR), split S over input-channel chunks.
+// Cost in MFMA-times per SIMD: rounds of workgroups x (chunks x MFMAs per chunk + a per-workgroup prologue/epilogue) + a
+// reduce launch.  A pure function of the descriptor and the workspace size (dvc_conv2d_winograd_split exposes S).
+static void wino_plan(const DvcConvDesc* d, int OH, int OW, bool have_workspace, size_t workspace_bytes, int* best_m_out,
+                      int* best_tr_out, int* best_S_out) {
+    const int ss = d->dil;
+    const int TY = cdiv(cdiv(OH, ss), 2), TX = cdiv(cdiv(OW, ss), 2);
+    const int ncu = conv_num_cus();
+    static const int kTR[4] = {1, 2, 4, 8};
+    int best_m = -1, best_tr = 1, best_S = 1;
+    double best_cost = 1e30;
+    const int shape_cfg = d->cfg >= 0 ? (d->cfg & 7) : -1;
+    for (int m = 0; m < 2; ++m) {
+        const int wm = m == 0 ? 4 : 2, wn = m == 0 ? 1 : 2, kc = m == 0 ? 4 : 8;
+        if (d->Cout % (32 * wm) != 0) continue;
+        if (shape_cfg >= 0 && shape_cfg / 4 != m) continue;
+        const int nch = d->Cin / kc;
+        for (int ti = 0; ti < 4; ++ti) {
+            const int tr = kTR[ti];
+            if (shape_cfg >= 0 && shape_cfg % 4 != ti) continue;
+            // (workgroups of ONE image: the plan never depends on the batch size, see conv2d_images)
+            const long wgs = (long)ss * ss * cdiv(TY, tr * wn) * cdiv(TX, 32 / tr) * (d->Cout / (32 * wm));
+            for (int S = 1; S <= 8; ++S) {
+                if (d->split_k > 0 && S != d->split_k) continue;
+                if (S > 1 && (!have_workspace || S > nch / 2 ||
+                              (size_t)S * d->Cout * OH * OW * sizeof(float) > workspace_bytes)) continue;
+                const int cps = cdiv(nch, S);
+                if (cdiv(nch, cps) != S) continue;
+                const double rounds = (double)cdivl(wgs * S, ncu);
+                double cost = rounds * (cps * (kc / 2) * 16.0 + 160.0) + (S > 1 ? 200.0 : 0.0);
+                cost *= 1.0 + 0.02 * ti;     // wider tile rows store better
+                if (cost < best_cost) { best_cost = cost; best_m = m; best_tr = tr; best_S = S; }
+            }
+        }
+    }
+    *best_m_out = best_m; *best_tr_out = best_tr; *best_S_out = best_S;
+}
+
+static int wino_check_desc(const DvcConvDesc* d) {
+    DVC_REQUIRE(d->ksize == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil,
+                "dvc_conv2d_winograd: needs a 3x3 stride-1 layer with pad == dilation (1 or 2)");
+    DVC_REQUIRE(!d->in_prelu, "dvc_conv2d_winograd: no fused input transform on this path");
+    DVC_REQUIRE((d->in_up == 1 || d->in_up == 2) && (d->in_sub == 1 || d->in_sub == 2) && !(d->in_up == 2 && d->in_sub == 2),
+                "dvc_conv2d_winograd: bad in_up/in_sub");
+    DVC_REQUIRE(d->N > 0 && d->Cin > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "dvc_conv2d_winograd: bad shape");
+    DVC_REQUIRE(d->Cin % 8 == 0 && d->Cout % 64 == 0, "dvc_conv2d_winograd: needs Cin %% 8 == 0 and Cout %% 64 == 0 (got %d, %d)",
+                d->Cin, d->Cout);
+    return 0;
+}
+
+extern "C" int dvc_conv2d_winograd_split(const DvcConvDesc* d, size_t workspace_bytes, int32_t* split) {
+    DVC_REQUIRE(d && split, "dvc_conv2d_winograd_split: null argument");
+    if (int rc = wino_check_desc(d)) return rc;
+    int32_t OH, OW;
+    dvc_conv2d_out_hw(d, &OH, &OW);
+    DVC_REQUIRE(OH > 0 && OW > 0, "dvc_conv2d_winograd_split: empty output");
+    int m, tr, S;
+    wino_plan(d, OH, OW, workspace_bytes > 0, workspace_bytes, &m, &tr, &S);
+    DVC_REQUIRE(m >= 0, "dvc_conv2d_winograd_split: no configuration for cfg %d / split_k %d on this layer", d->cfg, d->split_k);
+    // (the launch recomputes the split from the chunk count: same arithmetic as dvc_conv2d_winograd)
+    const int kc = m == 0 ? 4 : 8, nch = d->Cin / kc;
+    *split = cdiv(nch, cdiv(nch, S));
+    return 0;
+}
+
 extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const float* u_packed, const float* bias,
                                    const float* act_slope_ptr, const float* residual, float* y, void* workspace,
                                    size_t workspace_bytes, dvcStream stream) {
@@ -415,36 +480,8 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
     a.dbg = g_conv_dbg; a.dbg_buf = nullptr;
     s.ss = d->dil;
     const int TY = cdiv(cdiv(OH, s.ss), 2), TX = cdiv(cdiv(OW, s.ss), 2);   // 2x2 tiles of one parity class
-    const int ncu = conv_num_cus();
-    // candidates: workgroup shape m, tile-block shape TR x (32/TR), split S over input-channel chunks; cost in MFMA-times
-    // per SIMD: rounds of workgroups x (chunks x MFMAs per chunk + a per-workgroup prologue/epilogue) + a reduce launch
-    static const int kTR[4] = {1, 2, 4, 8};
     int best_m = -1, best_tr = 1, best_S = 1;
-    double best_cost = 1e30;
-    const int shape_cfg = d->cfg >= 0 ? (d->cfg & 7) : -1;
-    for (int m = 0; m < 2; ++m) {
-        const int wm = m == 0 ? 4 : 2, wn = m == 0 ? 1 : 2, kc = m == 0 ? 4 : 8;
-        if (d->Cout % (32 * wm) != 0) continue;
-        if (shape_cfg >= 0 && shape_cfg / 4 != m) continue;
-        const int nch = d->Cin / kc;
-        for (int ti = 0; ti < 4; ++ti) {
-            const int tr = kTR[ti];
-            if (shape_cfg >= 0 && shape_cfg % 4 != ti) continue;
-            // (workgroups of ONE image: the plan never depends on the batch size, see conv2d_images)
-            const long wgs = (long)s.ss * s.ss * cdiv(TY, tr * wn) * cdiv(TX, 32 / tr) * (d->Cout / (32 * wm));
-            for (int S = 1; S <= 8; ++S) {
-                if (d->split_k > 0 && S != d->split_k) continue;
-                if (S > 1 && (!workspace || S > nch / 2 ||
-                              (size_t)S * d->Cout * OH * OW * sizeof(float) > workspace_bytes)) continue;
-                const int cps = cdiv(nch, S);
-                if (cdiv(nch, cps) != S) continue;
-                const double rounds = (double)cdivl(wgs * S, ncu);
-                double cost = rounds * (cps * (kc / 2) * 16.0 + 160.0) + (S > 1 ? 200.0 : 0.0);
-                cost *= 1.0 + 0.02 * ti;     // wider tile rows store better
-                if (cost < best_cost) { best_cost = cost; best_m = m; best_tr = tr; best_S = S; }
-            }
-        }
-    }
+    wino_plan(d, OH, OW, workspace != nullptr, workspace_bytes, &best_m, &best_tr, &best_S);
     DVC_REQUIRE(best_m >= 0, "dvc_conv2d_winograd: no configuration for cfg %d / split_k %d on this layer", d->cfg, d->split_k);
     const int wm = best_m == 0 ? 4 : 2, wn = best_m == 0 ? 1 : 2, kc = best_m == 0 ? 4 : 8;
     const int nch = d->Cin / kc;
@@ -462,6 +499,10 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
     if (a.split > 1 && (size_t)d->N * a.split * per_img * sizeof(float) > workspace_bytes)
         group = (int)(workspace_bytes / ((size_t)a.split * per_img * sizeof(float)));
     DVC_REQUIRE(group > 0, "dvc_conv2d_winograd: split-K workspace too small for one image");
+    DVC_REQUIRE(!(d->flags & DVC_CONV_DEFER_REDUCE) || a.split == 1 || group >= d->N,
+                "dvc_conv2d_winograd: DVC_CONV_DEFER_REDUCE needs a workspace that holds the partial sums of the whole batch");
+    DVC_REQUIRE(!(d->flags & DVC_CONV_DEFER_REDUCE) || a.split == 1 || !residual,
+                "dvc_conv2d_winograd: DVC_CONV_DEFER_REDUCE does not carry a residual");
     for (int n0 = 0; n0 < d->N; n0 += group) {
         const int NB = std::min(group, d->N - n0);
         a.N = NB;
@@ -474,7 +515,7 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
         if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
         else conv_wino_launch_m2(best_tr, grid, st, s);
         DVC_CHECK_LAUNCH("dvc_conv2d_winograd");
-        if (a.split > 1) {
+        if (a.split > 1 && !(d->flags & DVC_CONV_DEFER_REDUCE)) {
             const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)NB * per_img) % 4 == 0);
             if (v4)
                 hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)((per_img / 4 + 255) / 256), NB), dim3(256), 0, st,

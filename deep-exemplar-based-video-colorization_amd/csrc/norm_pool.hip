@@ -117,20 +117,15 @@ extern "C" int dvc_instnorm_stats(const float* x, int32_t N, int32_t C, int32_t 
 // InstanceNorm + what follows it, one launch: the workgroup that reduced the plane also applies
 // y = prelu_or_id(x*scale + shift + residual) to it (second read from L2), with the output index maps of
 // affine_act_kernel plus stride-`sub` subsampling.
-__global__ __launch_bounds__(1024) void instnorm_apply_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ res,
-                                                              const float* __restrict__ slope_ptr,
-                                                              const float* __restrict__ chan_scale, float eps,
-                                                              int C, int H, int W, int up, int sub, int rpad,
-                                                              long x_bs, long res_bs, long y_bs,
-                                                              float* __restrict__ y, float* __restrict__ scale,
-                                                              float* __restrict__ shift,
-                                                              const float* __restrict__ chan_scale2, int sub2,
-                                                              long y2_bs, float* __restrict__ y2) {
-    __shared__ double red[36];
-    const int p = blockIdx.x;  // n*C + c
-    const int n = p / C, c = p - n * C;
-    const float* xp = x + (long)n * x_bs + (long)c * H * W;
+// (body shared by the two kernels below: `xp` is the plane to normalise — global memory, or the LDS image the partial-sum
+// variant has just built; generic pointer either way)
+__device__ __forceinline__ void instnorm_apply_plane(const float* xp, const int p, const int n, const int c, double* red,
+                                                     const float* __restrict__ res, const float* __restrict__ slope_ptr,
+                                                     const float* __restrict__ chan_scale, float eps, int C, int H, int W,
+                                                     int up, int sub, int rpad, long res_bs, long y_bs, float* __restrict__ y,
+                                                     float* __restrict__ scale, float* __restrict__ shift,
+                                                     const float* __restrict__ chan_scale2, int sub2, long y2_bs,
+                                                     float* __restrict__ y2) {
     float sc, sh;
     plane_stats(xp, H * W, eps, chan_scale ? chan_scale[c] : 1.f, red, &sc, &sh);
     if (threadIdx.x == 0 && scale) {
@@ -192,6 +187,76 @@ __global__ __launch_bounds__(1024) void instnorm_apply_kernel(const float* __res
     }
 }
 
+
+__global__ __launch_bounds__(1024) void instnorm_apply_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ res,
+                                                              const float* __restrict__ slope_ptr,
+                                                              const float* __restrict__ chan_scale, float eps,
+                                                              int C, int H, int W, int up, int sub, int rpad,
+                                                              long x_bs, long res_bs, long y_bs,
+                                                              float* __restrict__ y, float* __restrict__ scale,
+                                                              float* __restrict__ shift,
+                                                              const float* __restrict__ chan_scale2, int sub2,
+                                                              long y2_bs, float* __restrict__ y2) {
+    __shared__ double red[36];
+    const int p = blockIdx.x;  // n*C + c
+    const int n = p / C, c = p - n * C;
+    instnorm_apply_plane(x + (long)n * x_bs + (long)c * H * W, p, n, c, red, res, slope_ptr, chan_scale, eps, C, H, W, up, sub,
+                         rpad, res_bs, y_bs, y, scale, shift, chan_scale2, sub2, y2_bs, y2);
+}
+
+// The same, with the plane given as the S split-K partial sums a convolution left in its workspace (dvc_conv2d_winograd with
+// DVC_CONV_DEFER_REDUCE): x = act(sum_s part[s] + bias), summed in the reduce kernel's order (conv_splitk_reduce_kernel: the
+// result is bit-identical to reduce -> dvc_instnorm_apply), built once in LDS — the reduce launch, its write of the plane and
+// the two reads the statistics and the apply pass would make of it are gone.
+__global__ __launch_bounds__(1024) void instnorm_apply_partials_kernel(const float* __restrict__ part, int S, long slab,
+                                                                       const float* __restrict__ bias, int act, float act_slope,
+                                                                       const float* __restrict__ act_slope_ptr,
+                                                                       const float* __restrict__ res,
+                                                                       const float* __restrict__ slope_ptr,
+                                                                       const float* __restrict__ chan_scale, float eps,
+                                                                       int C, int H, int W, int up, int sub, int rpad,
+                                                                       long res_bs, long y_bs,
+                                                                       float* __restrict__ y, float* __restrict__ scale,
+                                                                       float* __restrict__ shift,
+                                                                       const float* __restrict__ chan_scale2, int sub2,
+                                                                       long y2_bs, float* __restrict__ y2) {
+    __shared__ double red[36];
+    extern __shared__ __attribute__((aligned(16))) float plane[];   // H * W floats
+    const int p = blockIdx.x;  // n*C + c
+    const int n = p / C, c = p - n * C;
+    const int HW = H * W;
+    const float* p0 = part + (long)p * HW;
+    const float b = bias ? bias[c] : 0.f;
+    const float aslope = act_slope_ptr ? *act_slope_ptr : act_slope;
+    auto finish = [&](float v) {
+        v += b;
+        if (act == DVC_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (act == DVC_ACT_PRELU || act == DVC_ACT_LEAKY) v = v >= 0.f ? v : v * aslope;
+        return v;
+    };
+    // float4 pieces, all S loads of a piece in flight (S <= 8), summed in the reduce kernel's order
+    const bool v4 = (HW % 4 == 0) && (slab % 4 == 0) && ((reinterpret_cast<uintptr_t>(part) & 15) == 0);
+    const int HW4 = v4 ? HW : 0;
+    for (int i = threadIdx.x * 4; i < HW4; i += blockDim.x * 4) {
+        float4 t[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) t[s] = s < S ? *reinterpret_cast<const float4*>(p0 + (long)s * slab + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { v.x += t[s].x; v.y += t[s].y; v.z += t[s].z; v.w += t[s].w; }
+        *reinterpret_cast<float4*>(plane + i) = make_float4(finish(v.x), finish(v.y), finish(v.z), finish(v.w));
+    }
+    for (int i = HW4 + threadIdx.x; i < HW; i += blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += p0[(long)s * slab + i];
+        plane[i] = finish(v);
+    }
+    __syncthreads();
+    instnorm_apply_plane(plane, p, n, c, red, res, slope_ptr, chan_scale, eps, C, H, W, up, sub, rpad, res_bs, y_bs, y, scale,
+                         shift, chan_scale2, sub2, y2_bs, y2);
+}
+
 extern "C" int dvc_instnorm_apply(const float* x, const float* residual, const float* slope_ptr,
                                   const float* chan_scale, float eps, int32_t N, int32_t C, int32_t H,
                                   int32_t W, int32_t up, int32_t sub, int32_t rpad, int64_t x_batch_stride,
@@ -216,6 +281,34 @@ extern "C" int dvc_instnorm_apply(const float* x, const float* residual, const f
                        scale_out, shift_out, chan_scale2, y2 ? sub2 : 1,
                        (long)C * (sub2 == 2 ? (H + 1) / 2 : H) * (sub2 == 2 ? (W + 1) / 2 : W), y2);
     DVC_CHECK_LAUNCH("dvc_instnorm_apply");
+    return 0;
+}
+
+extern "C" int dvc_instnorm_apply_partials(const float* part, int32_t S, const float* bias, int32_t act, float act_slope,
+                                           const float* act_slope_ptr, const float* residual, const float* slope_ptr,
+                                           const float* chan_scale, float eps, int32_t N, int32_t C, int32_t H, int32_t W,
+                                           int32_t up, int32_t sub, int32_t rpad, int64_t res_batch_stride,
+                                           int64_t y_batch_stride, float* y, float* scale_out, float* shift_out,
+                                           const float* chan_scale2, int32_t sub2, float* y2, dvcStream stream) {
+    DVC_REQUIRE(part && y && S >= 1 && S <= 8 && N > 0 && C > 0 && H > 0 && W > 0, "dvc_instnorm_apply_partials: bad argument");
+    DVC_REQUIRE((long)H * W <= 16384, "dvc_instnorm_apply_partials: plane of %d x %d does not fit the LDS image (<= 16384 elements)", H, W);
+    DVC_REQUIRE(act == DVC_ACT_NONE || act == DVC_ACT_RELU || act == DVC_ACT_PRELU || act == DVC_ACT_LEAKY,
+                "dvc_instnorm_apply_partials: unsupported activation %d", act);
+    DVC_REQUIRE(!y2 || ((sub2 == 1 || sub2 == 2) && y2 != y), "dvc_instnorm_apply_partials: bad second output");
+    DVC_REQUIRE(up >= 1 && up <= 4 && (sub == 1 || sub == 2) && rpad >= 0 && !(up != 1 && sub != 1),
+                "dvc_instnorm_apply_partials: bad up/sub/rpad");
+    DVC_REQUIRE(!(residual && (up != 1 || sub != 1)), "dvc_instnorm_apply_partials: residual requires up == sub == 1");
+    DVC_REQUIRE((scale_out == nullptr) == (shift_out == nullptr), "dvc_instnorm_apply_partials: scale/shift come together");
+    const long VH = sub == 2 ? (H + 1) / 2 : (long)H * up, VW = sub == 2 ? (W + 1) / 2 : (long)W * up;
+    const long OH = VH + 2 * rpad, OW = VW;
+    const long rbs = res_batch_stride ? res_batch_stride : (long)C * H * W;
+    const long ybs = y_batch_stride ? y_batch_stride : (long)C * OH * OW;
+    // (more threads per plane than the plain kernel: the partial sums are S x the plane, all of it first-touch traffic)
+    hipLaunchKernelGGL(instnorm_apply_partials_kernel, dim3(N * C), dim3(H * W >= 4096 ? 1024 : 512), (size_t)H * W * sizeof(float),
+                       (hipStream_t)stream, part, S, (long)N * C * H * W, bias, act, act_slope, act_slope_ptr, residual, slope_ptr,
+                       chan_scale, eps, C, H, W, up, sub, rpad, rbs, ybs, y, scale_out, shift_out, chan_scale2, y2 ? sub2 : 1,
+                       (long)C * (sub2 == 2 ? (H + 1) / 2 : H) * (sub2 == 2 ? (W + 1) / 2 : W), y2);
+    DVC_CHECK_LAUNCH("dvc_instnorm_apply_partials");
     return 0;
 }
 

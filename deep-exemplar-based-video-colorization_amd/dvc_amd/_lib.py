@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvc_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -23,6 +23,7 @@ class DvcConvDesc(ctypes.Structure):
         ("pad", c_i32), ("pad_mode", c_i32), ("in_up", c_i32), ("in_sub", c_i32),
         ("act", c_i32), ("act_slope", ctypes.c_float), ("in_prelu", c_i32), ("cfg", c_i32), ("split_k", c_i32),
         ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("res_batch_stride", c_i64),
+        ("flags", c_i32),
     ]
 
 
@@ -36,6 +37,7 @@ SIGNATURES = {
                                   ctypes.c_size_t, _VP]),
     "dvc_winograd_weight_floats": (ctypes.c_size_t, [c_i32, c_i32]),
     "dvc_winograd_pack_weight": (ctypes.c_int, [_VP, c_i32, c_i32, _VP, _VP]),
+    "dvc_conv2d_winograd_split": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), ctypes.c_size_t, ctypes.POINTER(c_i32)]),
     "dvc_conv2d_winograd": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                            ctypes.c_size_t, _VP]),
     "dvc_conv1x1_small": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, _VP, _VP]),
@@ -52,6 +54,9 @@ SIGNATURES = {
     "dvc_cx_ds": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,
                                  c_i32, ctypes.c_float, _VP, _VP, _VP]),
     "dvc_cx_normalize_bwd": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP]),
+    "dvc_instnorm_apply_partials": (ctypes.c_int, [_VP, c_i32, _VP, c_i32, ctypes.c_float, _VP, _VP, _VP, _VP, ctypes.c_float,
+                                                   c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, _VP, _VP, _VP,
+                                                   _VP, c_i32, _VP, _VP]),
     "dvc_maxpool2x2": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),
     "dvc_avgpool2x2": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),
     "dvc_avgpool4x4": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),

@@ -64,6 +64,12 @@ def _prepack(cache, key, conv):
         get("winograd")
 
 
+def _norm_in_place(t, **kw):
+    """InstanceNorm (+ what follows) of a convolution output, in place — or, when the convolution left its split-K partial
+    sums for this launch to add up (ops.ConvPartials), into a new tensor."""
+    return ops.instnorm_apply(t, out=None if isinstance(t, ops.ConvPartials) else t, **kw)
+
+
 def _check_input(x, name):
     if not x.is_cuda:
         raise RuntimeError(f"{name}: input is on {x.device}; the MI355X HIP path has no CPU fallback "
@@ -239,13 +245,14 @@ class WarpNet(nn.Module):
             seq = getattr(self, name)
             (ia, _, _, _, pa), (ib, _, _, sb, pb) = spec["convs"]
             ca, cb = seq[ia], seq[ib]
-            t = self._conv3(f"{name}.{ia}", ca, x, pad_mode=ops.PAD_REFLECT)
+            t = self._conv3(f"{name}.{ia}", ca, x, pad_mode=ops.PAD_REFLECT, defer_reduce=sb == 1)
             # InstanceNorm + PReLU are materialised (one launch, in place) so that the next convolution
             # has no fused input transform and stages through LDS-DMA; the stride-2 convolution
             # (run-time-geometry kernel, register staging anyway) applies them on load instead
             if sb == 1:
-                ops.instnorm_apply(t, slope_t=seq[pa].weight.detach(), out=t)
-                t = self._conv3(f"{name}.{ib}", cb, t, pad_mode=ops.PAD_REFLECT, in_up=2 if spec["up_mid"] else 1)
+                t = _norm_in_place(t, slope_t=seq[pa].weight.detach())
+                t = self._conv3(f"{name}.{ib}", cb, t, pad_mode=ops.PAD_REFLECT, in_up=2 if spec["up_mid"] else 1,
+                                defer_reduce=True)
             else:
                 sc, sh = ops.instnorm_stats(t)
                 t = ops.conv2d(t, self._pk(f"{name}.{ib}", cb), cb.bias.detach(), stride=sb,
@@ -258,10 +265,10 @@ class WarpNet(nn.Module):
         for b in range(arch.WARP_NUM_RESBLOCKS):
             blk = self.layer[b]
             a = blk.prelu.weight.detach()
-            t = self._conv3(f"layer.{b}.conv1", blk.conv1, x, pad_mode=ops.PAD_REFLECT)
-            ops.instnorm_apply(t, slope_t=a, out=t)
-            t = self._conv3(f"layer.{b}.conv2", blk.conv2, t, pad_mode=ops.PAD_REFLECT)
-            x = ops.instnorm_apply(t, residual=x, slope_t=a, out=t)
+            t = self._conv3(f"layer.{b}.conv1", blk.conv1, x, pad_mode=ops.PAD_REFLECT, defer_reduce=True)
+            t = _norm_in_place(t, slope_t=a)
+            t = self._conv3(f"layer.{b}.conv2", blk.conv2, t, pad_mode=ops.PAD_REFLECT, defer_reduce=True)
+            x = _norm_in_place(t, residual=x, slope_t=a)
         return x
 
     def project(self, which, feats, bf16=False):
@@ -404,6 +411,19 @@ class ColorVidNet(nn.Module):
                                                    sub=2 if ss_key else 1)
             return normed[k]
 
+        # activations that are only ever read through an InstanceNorm: normalised right after the convolution that
+        # produces them, which may then leave its split-K partial sums for the InstanceNorm launch to add up
+        norm_uses = {}
+        raw_use = set()
+        for c in arch.CVN_CONVS:
+            if c["pre"] in ("norm", "norm_ss", "up"):
+                norm_uses.setdefault(c["src"], []).append(c["ss"] if c["pre"] == "norm_ss" else None)
+            else:
+                raw_use.add(c["src"])
+            if c["add"] is not None:
+                raw_use.add(c["add"])
+        raw_use.add(arch.CVN_OUT.get("src", "c10_2"))
+
         act_map = {"relu": ops.ACT_RELU, "none": ops.ACT_NONE, "leaky": ops.ACT_LEAKY}
         for c in arch.CVN_CONVS:
             conv = self._mod(c["key"])
@@ -419,6 +439,14 @@ class ColorVidNet(nn.Module):
                 kw["in_up"] = 2
             if c["add"] is not None:
                 kw["residual"] = acts[c["add"]]
-            acts[c["dst"]] = ops.conv3x3(src, conv.weight, _packs(self._cache, c["key"], conv.weight), conv.bias.detach(), **kw)
+            dst = c["dst"]
+            acts[dst] = ops.conv3x3(src, conv.weight, _packs(self._cache, c["key"], conv.weight), conv.bias.detach(),
+                                    defer_reduce=dst in norm_uses and dst not in raw_use, **kw)
+            if dst in norm_uses:
+                if dst in both:
+                    norm_of(dst)
+                else:
+                    for ss_key in dict.fromkeys(norm_uses[dst]):
+                        norm_of(dst, ss_key)
         out = self._mod(arch.CVN_OUT["key"])
         return ops.conv1x1_small(acts["c10_2"], self._out_weight(), out.bias.detach(), act=ops.ACT_TANH128)

@@ -147,6 +147,8 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
                                 pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, affine=in_scale is not None,
                                 in_prelu=in_slope_t is not None, residual=residual is not None, act=act))
     ws = _workspace(x.device, CONV_WORKSPACE_BYTES, "conv")
+    global _conv_ws_generation
+    _conv_ws_generation += 1
     rc = lib.dvc_conv2d(ctypes.byref(d), _p(x), _p(w_packed), _p(bias), _p(in_scale), _p(in_shift),
                         _p(in_slope_t), _p(act_slope_t), _p(residual), _p(out),
                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
@@ -174,9 +176,30 @@ def winograd_eligible(Cin, Cout, ksize=3, stride=1, dil=1, pad=1, in_affine=Fals
             and Cin % 8 == 0 and Cout % 64 == 0)
 
 
+DEFER_REDUCE = 1     # DVC_CONV_DEFER_REDUCE
+_conv_ws_generation = 0
+
+
+class ConvPartials:
+    """What conv2d_winograd(..., defer_reduce=True) returns for a layer that is split over input channels: the partial sums
+    [S][N][C][H*W] sitting in the stream's convolution workspace, with the bias / activation still to be applied.  Valid
+    until the next convolution on the same stream reuses the workspace; the one consumer is instnorm_apply."""
+
+    def __init__(self, ws, S, shape, bias, act, act_slope, act_slope_t, generation, device):
+        self.ws, self.S, self.shape, self.bias = ws, S, tuple(shape), bias
+        self.act, self.act_slope, self.act_slope_t, self.generation, self.device = act, act_slope, act_slope_t, generation, device
+
+    def check_live(self):
+        if self.generation != _conv_ws_generation:
+            raise RuntimeError("dvc_amd: the convolution workspace holding these partial sums has been reused by a later "
+                               "convolution; instnorm_apply must directly follow conv3x3(defer_reduce=True)")
+
+
 def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1, act=ACT_NONE, act_slope=0.0,
-                    act_slope_t=None, residual=None, out=None, out_batch_stride=0, cfg=-1, split_k=0):
-    """dvc_conv2d_winograd: 3x3, stride 1, pad == dil.  u_packed from pack_winograd_weight."""
+                    act_slope_t=None, residual=None, out=None, out_batch_stride=0, cfg=-1, split_k=0, defer_reduce=False):
+    """dvc_conv2d_winograd: 3x3, stride 1, pad == dil.  u_packed from pack_winograd_weight.
+    defer_reduce=True: if the library splits this layer over input channels, skip the reduce launch and return the
+    ConvPartials for instnorm_apply to sum (otherwise the ordinary output tensor)."""
     lib = _lib.load()
     for t, nm in ((x, "x"), (u_packed, "u_packed"), (bias, "bias"), (act_slope_t, "act_slope"), (residual, "residual")):
         _need(t, nm)
@@ -184,20 +207,36 @@ def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_
     assert u_packed.dim() == 5 and u_packed.shape[1] == Cin and tuple(u_packed.shape[2:]) == (4, 32, 4), u_packed.shape
     Cout = u_packed.shape[0] * 32
     OH, OW = conv_out_hw(H, W, 3, 1, dil, dil, in_up, in_sub)
-    if out is None:
-        out = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
+    if out is not None:
+        defer_reduce = False
     if residual is not None:
         assert tuple(residual.shape) == (N, Cout, OH, OW), (residual.shape, (N, Cout, OH, OW))
     d = DvcConvDesc(N, Cin, H, W, Cout, 3, 1, dil, dil, pad_mode, in_up, in_sub, act, float(act_slope), 0, cfg, split_k,
-                    0, out_batch_stride, 0)
+                    0, out_batch_stride, 0, 0)
     if conv_record is not None:
         conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=3, stride=1, dil=dil, pad=dil, pad_mode=pad_mode,
                                 in_up=in_up, in_sub=in_sub, affine=False, in_prelu=False, residual=residual is not None,
                                 act=act, algo="winograd"))
     ws = _workspace(x.device, CONV_WORKSPACE_BYTES, "conv")
-    rc = lib.dvc_conv2d_winograd(ctypes.byref(d), _p(x), _p(u_packed), _p(bias), _p(act_slope_t), _p(residual), _p(out),
+    global _conv_ws_generation
+    _conv_ws_generation += 1
+    S = 1
+    if defer_reduce and residual is None and OH * OW <= 16384 and act in (ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY):
+        sp = ctypes.c_int32(0)
+        _lib.check(lib.dvc_conv2d_winograd_split(ctypes.byref(d), ws.numel(), ctypes.byref(sp)), "dvc_conv2d_winograd_split")
+        S = sp.value
+        if S > 1 and S * N * Cout * OH * OW * 4 <= ws.numel():
+            d.flags = DEFER_REDUCE
+        else:
+            S = 1
+    if S == 1 and out is None:
+        out = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
+    rc = lib.dvc_conv2d_winograd(ctypes.byref(d), _p(x), _p(u_packed), _p(bias), _p(act_slope_t), _p(residual),
+                                 _p(out) if out is not None else ctypes.c_void_p(ws.data_ptr()),
                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     _lib.check(rc, "dvc_conv2d_winograd")
+    if S > 1:
+        return ConvPartials(ws, S, (N, Cout, OH, OW), bias, act, float(act_slope), act_slope_t, _conv_ws_generation, x.device)
     return out
 
 
@@ -206,6 +245,15 @@ def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_
 # profiles/r02_conv_wino_probe.txt (Winograd where it is measured faster).  The choice is a pure function of the layer
 # geometry, so the clip driver's pipelined and sequential orders still run the same kernels (bit-identical outputs).
 _conv_algo = _os.environ.get("DVC_CONV_ALGO", "auto")
+
+
+# conv -> InstanceNorm pairs: let the InstanceNorm launch sum the convolution's split-K partials (DVC_FUSE_REDUCE=0 disables)
+_fuse_reduce = _os.environ.get("DVC_FUSE_REDUCE", "1") == "1"
+
+
+def set_fuse_reduce(flag=True):
+    global _fuse_reduce
+    _fuse_reduce = bool(flag)
 
 
 def set_conv_algo(algo):
@@ -238,7 +286,7 @@ def _wino_rule(N, Cin, Cout, OH, OW, dil):
 
 
 def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1, act=ACT_NONE, act_slope=0.0,
-            act_slope_t=None, residual=None, out=None, out_batch_stride=0):
+            act_slope_t=None, residual=None, out=None, out_batch_stride=0, defer_reduce=False):
     """A 3x3 stride-1 pad == dil layer through whichever engine the algorithm choice selects.  `packs(kind)` returns
     the packed weight for kind "direct" ([Cin][9][Cout]) or "winograd" (U = G g G^T), normally from a _PackCache."""
     N, Cin, H, W = x.shape
@@ -246,7 +294,7 @@ def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub
     if winograd_selected(N, Cin, H, W, Cout, dil=dil, pad=dil, in_up=in_up, in_sub=in_sub):
         return conv2d_winograd(x, packs("winograd"), bias, dil=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub,
                                act=act, act_slope=act_slope, act_slope_t=act_slope_t, residual=residual, out=out,
-                               out_batch_stride=out_batch_stride)
+                               out_batch_stride=out_batch_stride, defer_reduce=defer_reduce and _fuse_reduce)
     return conv2d(x, packs("direct"), bias, dil=dil, pad=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, act=act,
                   act_slope=act_slope, act_slope_t=act_slope_t, residual=residual, out=out,
                   out_batch_stride=out_batch_stride)
@@ -351,18 +399,31 @@ def instnorm_apply(x, *, eps=1e-5, chan_scale=None, residual=None, slope_t=None,
     `second=(chan_scale2, sub2)` also returns InstanceNorm(x) * chan_scale2 at stride sub2 (same statistics,
     same launch): the call then returns (y, y2)."""
     lib = _lib.load()
+    part = x if isinstance(x, ConvPartials) else None
+    if part is not None:
+        part.check_live()
+        assert out is None or not isinstance(out, ConvPartials)
+        x = None
     for t, nm in ((x, "x"), (chan_scale, "chan_scale"), (residual, "residual"), (slope_t, "slope")):
         _need(t, nm)
-    N, C, H, W = x.shape
+    N, C, H, W = part.shape if part is not None else x.shape
+    dev = part.device if part is not None else x.device
     VH, VW = ((H + 1) // 2, (W + 1) // 2) if sub == 2 else (H * up, W * up)
     if out is None:
-        out = torch.empty((N, C, VH + 2 * rpad, VW), device=x.device, dtype=torch.float32)
+        out = torch.empty((N, C, VH + 2 * rpad, VW), device=dev, dtype=torch.float32)
     cs2, sub2, y2 = None, 1, None
     if second is not None:
         cs2, sub2 = second
         _need(cs2, "chan_scale2")
-        y2 = torch.empty((N, C, (H + 1) // 2, (W + 1) // 2) if sub2 == 2 else (N, C, H, W), device=x.device,
+        y2 = torch.empty((N, C, (H + 1) // 2, (W + 1) // 2) if sub2 == 2 else (N, C, H, W), device=dev,
                          dtype=torch.float32)
+    if part is not None:
+        _lib.check(lib.dvc_instnorm_apply_partials(ctypes.c_void_p(part.ws.data_ptr()), part.S, _p(part.bias), part.act,
+                                                   part.act_slope, _p(part.act_slope_t), _p(residual), _p(slope_t),
+                                                   _p(chan_scale), float(eps), N, C, H, W, up, sub, rpad, 0, out_batch_stride,
+                                                   _p(out), None, None, _p(cs2), sub2, _p(y2), _stream()),
+                   "dvc_instnorm_apply_partials")
+        return out if second is None else (out, y2)
     _lib.check(lib.dvc_instnorm_apply(_p(x), _p(residual), _p(slope_t), _p(chan_scale), float(eps), N, C, H, W, up,
                                       sub, rpad, 0, 0, out_batch_stride, _p(out), None, None, _p(cs2), sub2,
                                       _p(y2), _stream()),

@@ -27,7 +27,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 8
+#define DVC_ABI_VERSION 9
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -86,7 +86,12 @@ typedef struct DvcConvDesc {
     int64_t x_batch_stride;     /* elements; 0 => Cin*H*W */
     int64_t y_batch_stride;     /* elements; 0 => Cout*OH*OW  (lets y be a channel slice) */
     int64_t res_batch_stride;   /* elements; 0 => Cout*OH*OW */
+    int32_t flags;              /* DVC_CONV_* bits (0 = none) */
 } DvcConvDesc;
+/* dvc_conv2d_winograd only: when the layer is split over input channels (dvc_conv2d_winograd_split > 1), leave the partial
+ * sums [split][N][Cout][OH*OW] in the workspace instead of launching the reduce — bias, activation and `y` are then NOT applied /
+ * written; the consumer sums them (dvc_instnorm_apply_partials).  No effect when the layer is not split. */
+#define DVC_CONV_DEFER_REDUCE 1
 
 /* Output spatial size implied by a descriptor. */
 int dvc_conv2d_out_hw(const DvcConvDesc* d, int32_t* OH, int32_t* OW);
@@ -114,6 +119,8 @@ size_t dvc_winograd_weight_floats(int32_t Cout, int32_t Cin);
 /* w: [Cout][Cin][3][3] (the nn.Conv2d weight as stored in the reference's checkpoints) -> u_packed, evaluated in double
  * and rounded once.  Cout % 32 == 0. */
 int dvc_winograd_pack_weight(const float* w, int32_t Cout, int32_t Cin, float* u_packed, dvcStream stream);
+/* the split over input channels dvc_conv2d_winograd uses for this descriptor and workspace size (1 = none); a pure function */
+int dvc_conv2d_winograd_split(const DvcConvDesc* d, size_t workspace_bytes, int32_t* split);
 int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const float* u_packed,
                         const float* bias /* may be NULL */, const float* act_slope_ptr /* device scalar or NULL */,
                         const float* residual /* or NULL */, float* y,
@@ -160,6 +167,15 @@ int dvc_instnorm_apply(const float* x, const float* residual /* or NULL */, cons
                        float* scale_out, float* shift_out,
                        const float* chan_scale2 /* [C] or NULL */, int32_t sub2, float* y2 /* or NULL */,
                        dvcStream stream);
+/* dvc_instnorm_apply on x = act(sum_s part[s] + bias): `part` = the [S][N][C][H*W] partial sums a convolution left in its
+ * workspace (DVC_CONV_DEFER_REDUCE), bias [C] or NULL, act / act_slope / act_slope_ptr as DvcConvDesc.  Bit-identical to
+ * reduce -> dvc_instnorm_apply; one launch and three passes over the tensor less.  H*W <= 16384 (the plane is built in LDS). */
+int dvc_instnorm_apply_partials(const float* part, int32_t S, const float* bias, int32_t act, float act_slope,
+                                const float* act_slope_ptr, const float* residual, const float* slope_ptr,
+                                const float* chan_scale, float eps, int32_t N, int32_t C, int32_t H, int32_t W, int32_t up,
+                                int32_t sub, int32_t rpad, int64_t res_batch_stride, int64_t y_batch_stride, float* y,
+                                float* scale_out, float* shift_out, const float* chan_scale2, int32_t sub2, float* y2,
+                                dvcStream stream);
 
 /* nn.MaxPool2d(2,2) floor mode, NonlocalNet.py:237-255. planes = N*C. */
 int dvc_maxpool2x2(const float* x, int32_t planes, int32_t H, int32_t W, float* y, dvcStream stream);

@@ -189,8 +189,28 @@ def test_warpnet_exemplar_cache_is_bit_identical(nets, weights):
     assert torch.equal(y0, y1) and torch.equal(s0, s1)
 
 
+@pytest.fixture
+def conv_algo(request):
+    """Run a test under a given convolution algorithm choice (ops.set_conv_algo) and restore the default afterwards."""
+    from dvc_amd import ops
+    old = ops.conv_algo()
+    ops.set_conv_algo(request.param)
+    yield request.param
+    ops.set_conv_algo(old)
+
+
+# With plain random weights the network amplifies rounding noise ~70x (dvc_amd/synth.py), so these two tests bound the GPU's
+# distance from the fp64 truth by a multiple of the reference-equivalent CPU fp32 run's distance.  The direct engine sits
+# at or below the CPU run; Winograd F(2x2,3x3) carries 2.3x the rounding error of a direct fp32 sum per layer
+# (csrc/conv_wino_kernel.h, measured) — the same trade cuDNN makes for the reference under cudnn.benchmark (test.py:140) —
+# so its worst-case statistics get 2.5x, its mean still 1.5x.  The literal 1e-3 claim is asserted on the well-conditioned
+# weights in tests/test_gpu_e2e.py, with the default (Winograd) algorithm.
+WORST_CASE_FACTOR = {"direct": 1.5, "auto": 2.5}
+
+
+@pytest.mark.parametrize("conv_algo", ["auto", "direct"], indirect=True)
 @pytest.mark.parametrize("H,W", [(48, 80), (216, 384)])
-def test_colorvidnet(nets, weights, H, W):
+def test_colorvidnet(nets, weights, H, W, conv_algo):
     from oracle import dvc_oracle as O
     col = nets[2]
     g = torch.Generator().manual_seed(9)
@@ -201,13 +221,13 @@ def test_colorvidnet(nets, weights, H, W):
     got = col(x.cuda())
     e_gpu = (got.double().cpu() - ref64).abs()
     e_cpu = (ref32.double() - ref64).abs()
-    report(f"colorvidnet {H}x{W}: gpu_vs_fp64 max={e_gpu.max():.2e} mean={e_gpu.mean():.2e} | "
+    report(f"colorvidnet {H}x{W} conv={conv_algo}: gpu_vs_fp64 max={e_gpu.max():.2e} mean={e_gpu.mean():.2e} | "
            f"cpu32_vs_fp64 max={e_cpu.max():.2e} mean={e_cpu.mean():.2e}")
     assert got.shape == ref32.shape
     # fp32 tolerance on the +-128-range output: within 1e-3 max-abs of the fp64 truth, or — where the
     # reference's own fp32 run is not (it is not, with these random weights) — no further from the
-    # truth than 1.5x the reference's fp32 run on the same input.
-    assert e_gpu.max().item() < max(1e-3, 1.5 * e_cpu.max().item())
+    # truth than a small multiple of the reference's fp32 run on the same input (see WORST_CASE_FACTOR).
+    assert e_gpu.max().item() < max(1e-3, WORST_CASE_FACTOR[conv_algo] * e_cpu.max().item())
     assert e_gpu.mean().item() < max(1e-4, 1.5 * e_cpu.mean().item())
 
 
@@ -274,11 +294,12 @@ def test_frame_colorization_vs_reference_golden(nets, golden_dir, name):
     assert clean_frames >= 1
 
 
+@pytest.mark.parametrize("conv_algo", ["auto", "direct"], indirect=True)
 @pytest.mark.parametrize("H,W,T", [(48, 80, 1e-10), (40, 64, 0.01), (216, 384, 1e-10)])
-def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights, H, W, T):
-    """The honest form of the "ab within 1e-3" claim (SURVEY.md §7 hard part 1): GPU-fp32 vs the fp64
-    truth, next to the reference-equivalent CPU-fp32 vs the same truth.  Pass = within 1e-3, or no
-    further from the truth than 1.5x the CPU fp32 run (mean and 99.9th percentile)."""
+def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights, H, W, T, conv_algo):
+    """The honest form of the "ab within 1e-3" claim with the chaotic random weights (SURVEY.md §7 hard part 1): GPU-fp32
+    vs the fp64 truth, next to the reference-equivalent CPU-fp32 vs the same truth.  Pass = within 1e-3, or no further
+    from the truth than 1.5x the CPU fp32 run in the mean and WORST_CASE_FACTOR x in the 99.9th percentile."""
     from dvc_amd import synth
     from oracle import dvc_oracle as O
     sd32 = weights
@@ -297,11 +318,11 @@ def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights, H, W, T):
     w_gpu = (warped[0].double().cpu() - nl64).abs()
     w_cpu = (nl32.double() - nl64).abs()
     q = lambda t: np.quantile(t.numpy(), 0.999)
-    report(f"e2e vs fp64 {H}x{W} T={T}: GPU ab max={e_gpu.max():.2e} q999={q(e_gpu):.2e} mean={e_gpu.mean():.2e} | "
+    report(f"e2e vs fp64 {H}x{W} T={T} conv={conv_algo}: GPU ab max={e_gpu.max():.2e} q999={q(e_gpu):.2e} mean={e_gpu.mean():.2e} | "
            f"CPU32 ab max={e_cpu.max():.2e} q999={q(e_cpu):.2e} mean={e_cpu.mean():.2e} | "
            f"warped GPU max={w_gpu.max():.2e} CPU32 max={w_cpu.max():.2e}")
     assert e_gpu.mean().item() < max(1e-3, 1.5 * e_cpu.mean().item())
-    assert q(e_gpu) < max(1e-3, 1.5 * q(e_cpu))
+    assert q(e_gpu) < max(1e-3, WORST_CASE_FACTOR[conv_algo] * q(e_cpu))
     assert w_gpu.max().item() < max(1e-3, 2.0 * w_cpu.max().item())
     if H <= 64:
         # report only: how a FREE-RUNNING second frame (IA_last = own previous prediction) diverges
@@ -542,3 +563,25 @@ def test_luminance_noise_path(nets):
     assert torch.equal(ab_n, ab_p) and torch.equal(nl_n, nl_p)
     ab_0, _, _ = frame_colorization(fr, IB, last, fB, vgg, warp, col, joint_training=False, temperature=T)
     assert (ab_0 - ab_n).abs().max().item() > 1e-3
+
+
+def test_fused_split_k_reduce_is_bit_identical_in_the_networks(nets, weights):
+    """WarpNet trunk and ColorVidNet with the split-K reduce folded into the InstanceNorm launches (default) against the same
+    networks with separate reduce launches (ops.set_fuse_reduce(False)): bit for bit."""
+    from dvc_amd import ops
+    vgg, warp, col = nets
+    g = torch.Generator().manual_seed(21)
+    feats = [torch.randn(1, c, h, w, generator=g).cuda() for c, h, w in ((128, 108, 192), (256, 54, 96), (512, 27, 48), (512, 13, 24))]
+    x = (torch.randn(1, 7, 216, 384, generator=g) * torch.tensor([30, 40, 40, 0.3, 30, 40, 40.]).view(1, 7, 1, 1)).cuda()
+    try:
+        ops.set_fuse_reduce(True)
+        ops.conv_record = []
+        a_w, a_c = warp.features(*feats), col(x)
+        rec, ops.conv_record = ops.conv_record, None
+        ops.set_fuse_reduce(False)
+        b_w, b_c = warp.features(*feats), col(x)
+    finally:
+        ops.set_fuse_reduce(True)
+        ops.conv_record = None
+    assert torch.equal(a_w, b_w) and torch.equal(a_c, b_c)
+    assert len(rec) > 30

@@ -587,3 +587,53 @@ def test_errors_are_loud(ops):
     with pytest.raises(ValueError):
         ops.corr_fwd(torch.zeros(1, 256, 16).cuda(), torch.zeros(1, 256, 16).cuda(), torch.zeros(1, 3, 16).cuda(),
                      0.0, 4, 4)
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,dil,act,mode", [
+    (256, 256, 54, 96, 1, 0, "prelu"), (512, 512, 27, 48, 1, 1, "plain"), (512, 512, 27, 48, 2, 1, "second"),
+    (256, 64, 27, 48, 1, 0, "up_rpad"), (128, 256, 54, 96, 1, 1, "ss"), (256, 256, 54, 96, 1, 0, "residual"),
+    (64, 64, 20, 36, 1, 1, "plain"), (64, 64, 136, 160, 1, 1, "plain"),
+])
+def test_instnorm_sums_deferred_split_k_partials(ops, Cin, Cout, H, W, dil, act, mode):
+    """conv2d_winograd(defer_reduce=True) leaves the split-K partial sums in the workspace and instnorm_apply adds them up
+    in the reduce kernel's order: BIT-IDENTICAL to conv (with its reduce launch) -> instnorm_apply, for every epilogue of
+    the InstanceNorm launch the networks use; a layer the library does not split simply returns its output tensor."""
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(2, Cin, H, W, generator=g).cuda()
+    u = ops.pack_winograd_weight((torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda())
+    b = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    slope = torch.tensor([0.2]).cuda()
+    kw = {}
+    if mode == "prelu":
+        kw = dict(slope_t=slope)
+    elif mode == "second":
+        kw = dict(second=(torch.rand(Cout, generator=g).cuda() + 0.5, 2))
+    elif mode == "up_rpad":
+        big = torch.zeros(2, Cout + 8, 2 * H + 2, 2 * W).cuda()
+        kw = dict(slope_t=slope, up=2, rpad=1)
+    elif mode == "ss":
+        kw = dict(chan_scale=torch.rand(Cout, generator=g).cuda() + 0.5, sub=2)
+    elif mode == "residual":
+        kw = dict(residual=torch.randn(2, Cout, H, W, generator=g).cuda(), slope_t=slope)
+
+    def run(defer):
+        t = ops.conv2d_winograd(x, u, b, dil=dil, act=act, defer_reduce=defer)
+        if mode == "up_rpad":
+            big.zero_()
+            ops.instnorm_apply(t, out=big[:, 4:4 + Cout], out_batch_stride=(Cout + 8) * (2 * H + 2) * 2 * W, **kw)
+            return (big.clone(),), t
+        r = ops.instnorm_apply(t, **kw)
+        return (r if isinstance(r, tuple) else (r,)), t
+    ref, t0 = run(False)
+    got, t1 = run(True)
+    assert isinstance(t0, torch.Tensor)
+    if H * W > 16384:
+        assert isinstance(t1, torch.Tensor)           # plane too large for the LDS image: the ordinary path
+    else:
+        assert isinstance(t1, ops.ConvPartials) and t1.S > 1, "this layer is split over input channels at one image per plan"
+    for a_, b_ in zip(ref, got):
+        assert torch.equal(a_, b_)
+    if isinstance(t1, ops.ConvPartials):       # a later convolution reuses the workspace: the partial sums are gone, and said so
+        ops.conv2d_winograd(x, u, b, dil=dil)
+        with pytest.raises(RuntimeError, match="reused"):
+            ops.instnorm_apply(t1)
