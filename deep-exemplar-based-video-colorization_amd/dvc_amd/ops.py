@@ -147,8 +147,7 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
                                 pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, affine=in_scale is not None,
                                 in_prelu=in_slope_t is not None, residual=residual is not None, act=act))
     ws = _workspace(x.device, CONV_WORKSPACE_BYTES, "conv")
-    global _conv_ws_generation
-    _conv_ws_generation += 1
+    _bump_generation(ws)
     rc = lib.dvc_conv2d(ctypes.byref(d), _p(x), _p(w_packed), _p(bias), _p(in_scale), _p(in_shift),
                         _p(in_slope_t), _p(act_slope_t), _p(residual), _p(out),
                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
@@ -177,7 +176,13 @@ def winograd_eligible(Cin, Cout, ksize=3, stride=1, dil=1, pad=1, in_affine=Fals
 
 
 DEFER_REDUCE = 1     # DVC_CONV_DEFER_REDUCE
-_conv_ws_generation = 0
+_conv_ws_generation = {}     # convolution workspace (one per device and stream) -> number of convolutions that have used it
+
+
+def _bump_generation(ws):
+    g = _conv_ws_generation.get(ws.data_ptr(), 0) + 1
+    _conv_ws_generation[ws.data_ptr()] = g
+    return g
 
 
 class ConvPartials:
@@ -190,7 +195,7 @@ class ConvPartials:
         self.act, self.act_slope, self.act_slope_t, self.generation, self.device = act, act_slope, act_slope_t, generation, device
 
     def check_live(self):
-        if self.generation != _conv_ws_generation:
+        if self.generation != _conv_ws_generation.get(self.ws.data_ptr()):
             raise RuntimeError("dvc_amd: the convolution workspace holding these partial sums has been reused by a later "
                                "convolution; instnorm_apply must directly follow conv3x3(defer_reduce=True)")
 
@@ -218,8 +223,7 @@ def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_
                                 in_up=in_up, in_sub=in_sub, affine=False, in_prelu=False, residual=residual is not None,
                                 act=act, algo="winograd"))
     ws = _workspace(x.device, CONV_WORKSPACE_BYTES, "conv")
-    global _conv_ws_generation
-    _conv_ws_generation += 1
+    generation = _bump_generation(ws)
     S = 1
     if defer_reduce and residual is None and OH * OW <= 16384 and act in (ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY):
         sp = ctypes.c_int32(0)
@@ -236,7 +240,7 @@ def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_
                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     _lib.check(rc, "dvc_conv2d_winograd")
     if S > 1:
-        return ConvPartials(ws, S, (N, Cout, OH, OW), bias, act, float(act_slope), act_slope_t, _conv_ws_generation, x.device)
+        return ConvPartials(ws, S, (N, Cout, OH, OW), bias, act, float(act_slope), act_slope_t, generation, x.device)
     return out
 
 
