@@ -167,7 +167,9 @@ __host__ __device__ __forceinline__ long corr_unit_owner(long u, long U, long G)
         CORR_CHAIN_LAST(MM);                                                                                \
     } while (0)
 
-template <bool WTA, bool VEC4>
+// SOFT: the soft-temperature organisation of the softmax step (T >= 1e-3, see (4s) below) as its own instantiation — as a
+// run-time branch next to the sharp / exact paths it costs the production kernel 35 registers and 20 spills.
+template <bool WTA, bool VEC4, bool SOFT = false>
 __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     // two key tiles (double buffer, 2 x 32 KB) + three pooled-Lab tiles [3][256] (first 96 floats used).
     // Three, because with ONE barrier per iteration the pending tile's Lab (read during the chain by slow
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     float mf = -INFINITY;    // running max affinity (after WTA / masking), exact
     float thr = -INFINITY;
     const float Tn = -a.T, ry = a.invT;
-    const bool sharp = 120.f * a.T < 1e-6f;   // wave-uniform: which organisation of step (4) pays
+    const bool sharp = !SOFT && 120.f * a.T < 1e-6f;   // wave-uniform: which organisation of step (4) pays
     auto div_T = [&](float f) {
         float q = f * ry;
         q = fmaf(fmaf(Tn, q, f), ry, q);
@@ -356,6 +358,35 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
                 }
                 return;
             }
+        }
+        // (4s) soft temperatures, T >= 1e-3 (the training-side values 0.01 / 0.005): every affinity contributes, and
+        // |f / T| <= 1000, where one fp32 ulp of s = fl32(f / T) is already 6e-5 — emulating the exact division (step 4b)
+        // buys nothing there.  p = exp(f / T - m) as ONE fma + ONE v_exp_f32 per affinity (log2 domain), no guards (a
+        // masked -inf gives exactly 0), and the arg-max bookkeeping once per tile instead of once per affinity:
+        // 6 instead of ~18 VALU per affinity, the same cost class as the sharp path.
+        if (SOFT) {
+            const float c1 = ry * 1.44269504088896f;
+            const float nm2 = (mf == -INFINITY) ? 0.f : -m * 1.44269504088896f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[r], c1, nm2));
+                l += pe;
+                y0 = fmaf(pe, blp[kl], y0);
+                y1 = fmaf(pe, blp[CORR_KT + kl], y1);
+                y2 = fmaf(pe, blp[2 * CORR_KT + kl], y2);
+            }
+            if (!WTA) {
+                const bool better = tmax > fmax;             // strict: an earlier tile keeps the arg-max on ties
+                if (__any(qvalid & better)) {
+                    int idx = 15;
+#pragma unroll
+                    for (int r = 14; r >= 0; --r) idx = (sacc[r] == tmax) ? r : idx;     // lowest key of the lane on ties
+                    fmax = better ? tmax : fmax;
+                    amax = better ? k0 + (idx & 3) + 8 * (idx >> 2) + 4 * hi : amax;
+                }
+            }
+            return;
         }
         // (4b) general case
 #pragma unroll
@@ -637,12 +668,17 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
     dim3 mgrid(cdiv(P, CORR_MQ), B);
     static_assert(CORR_QB % CORR_MQ == 0, "merge kernel assumes one query block per workgroup");
     const bool wta = wta_scale != 1.0f;
+    const bool soft = temperature >= 1e-3f;       // (4s): the training-side temperatures
     auto launch = [&](bool wta_pass) {
         if (wta_pass) {
-            if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
+            if (vec4 && soft) hipLaunchKernelGGL((corr_fwd_kernel<true, true, true>), grid, dim3(256), 0, s, a);
+            else if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
+            else if (soft) hipLaunchKernelGGL((corr_fwd_kernel<true, false, true>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((corr_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
         } else {
-            if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
+            if (vec4 && soft) hipLaunchKernelGGL((corr_fwd_kernel<false, true, true>), grid, dim3(256), 0, s, a);
+            else if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
+            else if (soft) hipLaunchKernelGGL((corr_fwd_kernel<false, false, true>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((corr_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
         }
     };
