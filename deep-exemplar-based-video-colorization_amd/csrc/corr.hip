@@ -169,7 +169,9 @@ __host__ __device__ __forceinline__ long corr_unit_owner(long u, long U, long G)
 
 // SOFT: the soft-temperature organisation of the softmax step (T >= 1e-3, see (4s) below) as its own instantiation — as a
 // run-time branch next to the sharp / exact paths it costs the production kernel 35 registers and 20 spills.
-template <bool WTA, bool VEC4, bool SOFT = false>
+// DBG: the timeline / timing-experiment hooks (dvc_debug_corr_timeline, dvc_debug_corr_variant) as their own instantiation
+// too: their pointers and per-tile tests live in SGPRs the production kernel is short of.
+template <bool WTA, bool VEC4, bool SOFT = false, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     // two key tiles (double buffer, 2 x 32 KB) + three pooled-Lab tiles [3][256] (first 96 floats used).
     // Three, because with ONE barrier per iteration the pending tile's Lab (read during the chain by slow
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     long u = corr_unit_start(wlog, a.U, G);
     const long u_end = corr_unit_start(wlog + 1, a.U, G);
     long long* dbgh = nullptr;  // debug header slot: [entry, loop start, loop end, exit] of the first segment
-    if (a.dbg && tid == 0) {
+    if (DBG && a.dbg && tid == 0) {
         dbgh = a.dbg + ((long)blockIdx.x * a.dbg_tiles + (a.dbg_tiles - 1)) * 4;
         dbgh[0] = __builtin_amdgcn_s_memtime();
     }
@@ -334,16 +336,19 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         // (3 VALU per affinity, no branches); unless some lane has two, a single update per TILE replaces
         // the per-affinity steps of (4b) — the terms it skips are exact zeros, so the sums are bit-identical.
         if (sharp) {
-            int cnt = 0, idx = 0;
+            // (count first, locate afterwards by equality with the tile maximum — the one candidate of a lane IS its tile
+            // maximum: keeping the 16 compare masks alive for a fused count-and-locate loop costs 32 SGPRs and sends the
+            // kernel's scalar state through v_writelane / v_readlane spills)
+            int cnt = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool c = qvalid & (sacc[r] >= thr);
-                cnt += c ? 1 : 0;
-                idx = c ? r : idx;
-            }
+            for (int r = 0; r < 16; ++r) cnt += (sacc[r] >= thr) ? 1 : 0;
+            cnt = qvalid ? cnt : 0;
             if (!__any(cnt > 1)) {
                 if (__any(cnt == 1)) {
                     const bool has = cnt == 1;   // (tmax is then finite: a masked -inf never passes a finite guard)
+                    int idx = 15;
+#pragma unroll
+                    for (int r = 14; r >= 0; --r) idx = (sacc[r] == tmax) ? r : idx;
                     const int kl = (idx & 3) + 8 * (idx >> 2) + 4 * hi;
                     const float pe = has ? __expf(div_T(tmax) - m) : 0.f;
                     l += pe;
@@ -424,13 +429,13 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     if (t0 < t1) commit(0, 0);
     __builtin_amdgcn_s_waitcnt(0xC07F);   // vmcnt(63) expcnt(7) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
-    if (dbgh) dbgh[1] = __builtin_amdgcn_s_memtime();
+    if (DBG && dbgh) dbgh[1] = __builtin_amdgcn_s_memtime();
     long long* dbgp = nullptr;
-    if (a.dbg && tid == 0)
+    if (DBG && a.dbg && tid == 0)
         dbgp = a.dbg + (long)blockIdx.x * a.dbg_tiles * 4;
     for (int t = t0; t < t1; ++t) {
         const int cur = (t - t0) & 1;
-        if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 0] = __builtin_amdgcn_s_memtime();
+        if (DBG && dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 0] = __builtin_amdgcn_s_memtime();
         issue(min(t + 1, t1 - 1), cur ^ 1);  // (the last iteration re-stages its own tile: harmless)
 
         // S^T tile of THIS key tile: 128 dependent MFMAs (K = 256), one basic block; the A fragments are
@@ -446,14 +451,14 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
                      : [addr] "v"(kaddr)
                      : "memory");
         CORR_CHAIN_ALL(CORR_MM1);
-        if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 1] = __builtin_amdgcn_s_memtime();
-        if (a.dbg_variant != 1) process_tile(acc, t * CORR_KT, bl + ((t - t0) % 3) * 256);
-        if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 2] = __builtin_amdgcn_s_memtime();
+        if (DBG && dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 1] = __builtin_amdgcn_s_memtime();
+        if (!DBG || a.dbg_variant != 1) process_tile(acc, t * CORR_KT, bl + ((t - t0) % 3) * 256);
+        if (DBG && dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 2] = __builtin_amdgcn_s_memtime();
         commit(cur ^ 1, (t + 1 - t0) % 3);
         __syncthreads();  // next tile landed (DMA drained / stores visible); this tile's reads done
-        if (dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 3] = __builtin_amdgcn_s_memtime();
+        if (DBG && dbgp && t - t0 < a.dbg_tiles - 1) dbgp[(t - t0) * 4 + 3] = __builtin_amdgcn_s_memtime();
     }
-    if (dbgh) dbgh[2] = __builtin_amdgcn_s_memtime();
+    if (DBG && dbgh) dbgh[2] = __builtin_amdgcn_s_memtime();
 
     // ---- combine the two key halves of the wave (lanes l and l^32 hold different keys of the SAME query) and write
     // the partial state of this (workgroup, query block) pair: slot = workgroup - first workgroup of the query block.
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         pp[5L * P] = fmax;
         pp[6L * P] = __int_as_float(amax);
     }
-    if (dbgh) {
+    if (DBG && dbgh) {
         dbgh[3] = __builtin_amdgcn_s_memtime();
         dbgh = nullptr;
     }
@@ -677,6 +682,7 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
             else hipLaunchKernelGGL((corr_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
         } else {
             if (vec4 && soft) hipLaunchKernelGGL((corr_fwd_kernel<false, true, true>), grid, dim3(256), 0, s, a);
+            else if (vec4 && (a.dbg || a.dbg_variant)) hipLaunchKernelGGL((corr_fwd_kernel<false, true, false, true>), grid, dim3(256), 0, s, a);
             else if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
             else if (soft) hipLaunchKernelGGL((corr_fwd_kernel<false, false, true>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((corr_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
