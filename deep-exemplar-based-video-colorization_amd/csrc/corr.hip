@@ -350,7 +350,11 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
 #pragma unroll
                     for (int r = 14; r >= 0; --r) idx = (sacc[r] == tmax) ? r : idx;
                     const int kl = (idx & 3) + 8 * (idx >> 2) + 4 * hi;
-                    const float pe = has ? __expf(div_T(tmax) - m) : 0.f;
+                    // (a candidate that IS the lane's running maximum — the usual case: its max has just risen, or ties an
+                    // earlier tile's — has s == m and p = exp(0) = 1 exactly; the division / exponential only run when some
+                    // lane's candidate sits below its maximum inside the guard window)
+                    float pe = has ? 1.f : 0.f;
+                    if (__any(has & (tmax != mf))) pe = has ? __expf(div_T(tmax) - m) : 0.f;
                     l += pe;
                     y0 = fmaf(pe, blp[kl], y0);
                     y1 = fmaf(pe, blp[CORR_KT + kl], y1);
