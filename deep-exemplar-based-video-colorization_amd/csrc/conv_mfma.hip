@@ -511,6 +511,14 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
         a.res = residual ? residual + (long)n0 * a.res_bs : nullptr;
         s.gz = NB * a.split;
         DVC_REQUIRE((long)s.gx * s.gy * s.gz < (1L << 31), "dvc_conv2d_winograd: grid too large");
+        {
+            const long G = (long)s.gx * s.gy * s.gz;
+            s.m_gxy = wino_magic((long)s.gx * s.gy, G);
+            s.m_gx = wino_magic(s.gx, (long)s.gx * s.gy);
+            s.m_cls = wino_magic((long)s.blk_y * s.blk_x, s.gx);
+            s.m_blkx = wino_magic(s.blk_x, (long)s.blk_y * s.blk_x);
+            s.m_split = wino_magic(a.split, s.gz);
+        }
         dim3 grid((unsigned)(s.gx * s.gy * s.gz));      // 1-D: the kernel maps it XCD-aware onto (gx, gy, gz)
         if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
         else conv_wino_launch_m2(best_tr, grid, st, s);

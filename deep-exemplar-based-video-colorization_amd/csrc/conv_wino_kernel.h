@@ -52,7 +52,16 @@ struct ConvWinoArgs {
     int ss;             // sub-grid step = dilation (1 | 2)
     int blk_y, blk_x;   // tile blocks per parity class
     int gx, gy, gz;     // logical grid: tile blocks x parity classes | channel blocks | images x input-channel splits
+    // ceil(2^32 / d) for the divisors of the workgroup-index decode (exact quotients by one s_mul_hi for numerators < 2^16;
+    // 0 = the numerator may be larger, divide properly): gx, gx * gy, blk_y * blk_x, blk_x, split
+    unsigned m_gx, m_gxy, m_cls, m_blkx, m_split;
 };
+__host__ __device__ __forceinline__ unsigned wino_magic(long d, long max_numerator) {
+    return (max_numerator < 65536 && d < 65536 && d > 1) ? (unsigned)(((1ULL << 32) + (unsigned long long)d - 1) / (unsigned long long)d) : 0u;
+}
+__device__ __forceinline__ int wino_div(int n, int d, unsigned magic) {
+    return magic ? (int)__umulhi((unsigned)n, magic) : (d == 1 ? n : n / d);
+}
 
 // LDS row pitch (floats) of the staged patch: even (8-byte aligned ds_read_b64) and such that the TR tile rows of a
 // 32-tile block start in disjoint bank ranges
@@ -146,21 +155,43 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
     const int G = s.gx * s.gy * s.gz;
     const int xq = G / 8, xr = G % 8, xcd = blockIdx.x % 8, xi = blockIdx.x / 8;
     const int wlog = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
-    const int bx = wlog % s.gx, by = (wlog / s.gx) % s.gy, bz = wlog / (s.gx * s.gy);
+    // (the decode is all wave-uniform integer division: by multiplication with host-made reciprocals — a plain `/` costs ~35
+    // VALU instructions each here, 1.5 us of every workgroup's life went into this prologue)
+    const int bz = wino_div(wlog, s.gx * s.gy, s.m_gxy), r_xy = wlog - bz * (s.gx * s.gy);
+    const int by = wino_div(r_xy, s.gx, s.m_gx), bx = r_xy - by * s.gx;
     const int per_cls = s.blk_y * s.blk_x;
-    const int cls = bx / per_cls, brem = bx % per_cls;
-    const int py = cls / ss, px = cls % ss;
-    const int ty0 = (brem / s.blk_x) * (TR * WN), tx0 = (brem % s.blk_x) * TC;
+    const int cls = wino_div(bx, per_cls, s.m_cls), brem = bx - cls * per_cls;
+    const int py = ss == 2 ? cls >> 1 : 0, px = ss == 2 ? cls & 1 : 0;
+    const int tyb = wino_div(brem, s.blk_x, s.m_blkx);
+    const int ty0 = tyb * (TR * WN), tx0 = (brem - tyb * s.blk_x) * TC;
     const int b0 = by * WM;
-    const int n = bz / a.split, ksplit = bz % a.split;
+    const int n = wino_div(bz, a.split, s.m_split), ksplit = bz - n * a.split;
     const int HWi = a.H * a.W;
 
     const int nchunks_all = a.Cin / KC;
     const int c_begin = ksplit * a.chunks_per_split;
     const int c_end = min(nchunks_all, c_begin + a.chunks_per_split);
 
-    // ---- staging plan (the same for every chunk; the chunk advance is the instruction's scalar offset)
+    // ---- staging plan (the same for every chunk; the chunk advance is the instruction's scalar offset).  The filter half
+    // comes first and its DMA for the first chunk is issued at once: it is 8x the bytes of the patch and cold (HBM / Infinity
+    // Cache), and its address plan is trivial — the round trip overlaps the index arithmetic of the patch plan below.
     int gofs[EPT], wrel[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int q = tid + i * NT;
+        wrel[i] = ((q / (KC * 128)) * a.Cin * 128 + q % (KC * 128)) * 16;
+    }
+    __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long)b0 * a.Cin * 512), 0, WM * a.Cin * 2048, 0x00020000);
+    auto issue_w = [&](int c, int buf) {
+        const int sw = c * KC * 2048;
+        float* us = usb + buf * (UQ * 4);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (CONV_AS3 void*)(us + (i * NT + wave * 64) * 4), 16, wrel[i], sw, 0, 0);
+    };
+    issue_w(c_begin, 0);
+    asm volatile(".set wino_i, 0\n\t.rept 128\n\tv_accvgpr_write_b32 a[wino_i], 0\n\t.set wino_i, wino_i + 1\n\t.endr" ::: WINO_AGPRS);
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
         const int e = tid + t * NT;
@@ -173,35 +204,26 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
         }
         gofs[t] = g >= 0 ? g * 4 : OOB;
     }
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-        const int q = tid + i * NT;
-        wrel[i] = ((q / (KC * 128)) * a.Cin * 128 + q % (KC * 128)) * 16;
-    }
-    __amdgpu_buffer_rsrc_t rs_w =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long)b0 * a.Cin * 512), 0, WM * a.Cin * 2048, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long)n * a.x_bs), 0, a.Cin * HWi * 4, 0x00020000);
-    auto issue = [&](int c, int buf) {
-        const int sx = c * KC * HWi * 4, sw = c * KC * 2048;
+    auto issue_x = [&](int c, int buf) {
+        const int sx = c * KC * HWi * 4;
         float* xs = xsb + buf * C_XS;
-        float* us = usb + buf * (UQ * 4);
 #pragma unroll
         for (int t = 0; t < EPT; ++t)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (CONV_AS3 void*)(xs + t * NT + wave * 64), 4, gofs[t], sx, 0, 0);
-#pragma unroll
-        for (int i = 0; i < WPT; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (CONV_AS3 void*)(us + (i * NT + wave * 64) * 4), 16, wrel[i], sw, 0, 0);
     };
-
-    asm volatile(".set wino_i, 0\n\t.rept 128\n\tv_accvgpr_write_b32 a[wino_i], 0\n\t.set wino_i, wino_i + 1\n\t.endr" ::: WINO_AGPRS);
+    auto issue = [&](int c, int buf) {
+        issue_x(c, buf);
+        issue_w(c, buf);
+    };
 
     // LDS byte addresses of the lane's operands inside buffer 0: patch rows ph .. ph + 2 of its tile, filter rows 2 ph, 2 ph + 1
     const unsigned xlane =
         (unsigned)(size_t)(CONV_AS3 float*)xsb + (hi * plane + (2 * (wn * TR + tr) + ph) * PITCH + 2 * tc) * 4;
     const unsigned ulane = (unsigned)(size_t)(CONV_AS3 float*)usb + (((wm * KC + hi) * 4 + 2 * ph) * 32 + l31) * 16;
 
-    issue(c_begin, 0);
+    issue_x(c_begin, 0);      // (the chunk's filter half is already in flight; NI instructions per chunk either way)
     if (c_begin + 1 < c_end) issue(c_begin + 1, 1);
     if (c_begin + 2 < c_end) issue(c_begin + 2, 2);
     if (c_begin + 2 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
