@@ -499,6 +499,11 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
     if (a.split > 1 && (size_t)d->N * a.split * per_img * sizeof(float) > workspace_bytes)
         group = (int)(workspace_bytes / ((size_t)a.split * per_img * sizeof(float)));
     DVC_REQUIRE(group > 0, "dvc_conv2d_winograd: split-K workspace too small for one image");
+    {   // the kernel decodes its workgroup index with 16-bit reciprocal multiplications: at most 65535 workgroups per launch
+        const long per_image = (long)s.gx * s.gy * a.split;
+        DVC_REQUIRE(per_image < 65536, "dvc_conv2d_winograd: %ld workgroups per image (feature map too large for this path)", per_image);
+        if ((long)group * per_image >= 65536) group = (int)(65535 / per_image);
+    }
     DVC_REQUIRE(!(d->flags & DVC_CONV_DEFER_REDUCE) || a.split == 1 || group >= d->N,
                 "dvc_conv2d_winograd: DVC_CONV_DEFER_REDUCE needs a workspace that holds the partial sums of the whole batch");
     DVC_REQUIRE(!(d->flags & DVC_CONV_DEFER_REDUCE) || a.split == 1 || !residual,
@@ -511,14 +516,11 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
         a.res = residual ? residual + (long)n0 * a.res_bs : nullptr;
         s.gz = NB * a.split;
         DVC_REQUIRE((long)s.gx * s.gy * s.gz < (1L << 31), "dvc_conv2d_winograd: grid too large");
-        {
-            const long G = (long)s.gx * s.gy * s.gz;
-            s.m_gxy = wino_magic((long)s.gx * s.gy, G);
-            s.m_gx = wino_magic(s.gx, (long)s.gx * s.gy);
-            s.m_cls = wino_magic((long)s.blk_y * s.blk_x, s.gx);
-            s.m_blkx = wino_magic(s.blk_x, (long)s.blk_y * s.blk_x);
-            s.m_split = wino_magic(a.split, s.gz);
-        }
+        s.m_gxy = wino_magic((long)s.gx * s.gy);
+        s.m_gx = wino_magic(s.gx);
+        s.m_cls = wino_magic((long)s.blk_y * s.blk_x);
+        s.m_blkx = wino_magic(s.blk_x);
+        s.m_split = wino_magic(a.split);
         dim3 grid((unsigned)(s.gx * s.gy * s.gz));      // 1-D: the kernel maps it XCD-aware onto (gx, gy, gz)
         if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
         else conv_wino_launch_m2(best_tr, grid, st, s);

@@ -52,16 +52,14 @@ struct ConvWinoArgs {
     int ss;             // sub-grid step = dilation (1 | 2)
     int blk_y, blk_x;   // tile blocks per parity class
     int gx, gy, gz;     // logical grid: tile blocks x parity classes | channel blocks | images x input-channel splits
-    // ceil(2^32 / d) for the divisors of the workgroup-index decode (exact quotients by one s_mul_hi for numerators < 2^16;
-    // 0 = the numerator may be larger, divide properly): gx, gx * gy, blk_y * blk_x, blk_x, split
+    // ceil(2^32 / d) for the divisors of the workgroup-index decode — exact quotients by one s_mul_hi for numerators and
+    // divisors < 2^16, which the launcher guarantees (it caps the images per launch): gx, gx * gy, blk_y * blk_x, blk_x, split
     unsigned m_gx, m_gxy, m_cls, m_blkx, m_split;
 };
-__host__ __device__ __forceinline__ unsigned wino_magic(long d, long max_numerator) {
-    return (max_numerator < 65536 && d < 65536 && d > 1) ? (unsigned)(((1ULL << 32) + (unsigned long long)d - 1) / (unsigned long long)d) : 0u;
+__host__ __device__ __forceinline__ unsigned wino_magic(long d) {      // (d == 1: 2^32 does not fit; 0 means "quotient = n")
+    return d > 1 ? (unsigned)(((1ULL << 32) + (unsigned long long)d - 1) / (unsigned long long)d) : 0u;
 }
-__device__ __forceinline__ int wino_div(int n, int d, unsigned magic) {
-    return magic ? (int)__umulhi((unsigned)n, magic) : (d == 1 ? n : n / d);
-}
+__device__ __forceinline__ int wino_div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
 
 // LDS row pitch (floats) of the staged patch: even (8-byte aligned ds_read_b64) and such that the TR tile rows of a
 // 32-tile block start in disjoint bank ranges
@@ -156,16 +154,16 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
     const int xq = G / 8, xr = G % 8, xcd = blockIdx.x % 8, xi = blockIdx.x / 8;
     const int wlog = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
     // (the decode is all wave-uniform integer division: by multiplication with host-made reciprocals — a plain `/` costs ~35
-    // VALU instructions each here, 1.5 us of every workgroup's life went into this prologue)
-    const int bz = wino_div(wlog, s.gx * s.gy, s.m_gxy), r_xy = wlog - bz * (s.gx * s.gy);
-    const int by = wino_div(r_xy, s.gx, s.m_gx), bx = r_xy - by * s.gx;
+    // instructions each here, and the prologue is instruction-bound: ~1.5 us of every workgroup's 32)
+    const int bz = wino_div(wlog, s.m_gxy), r_xy = wlog - bz * (s.gx * s.gy);
+    const int by = wino_div(r_xy, s.m_gx), bx = r_xy - by * s.gx;
     const int per_cls = s.blk_y * s.blk_x;
-    const int cls = wino_div(bx, per_cls, s.m_cls), brem = bx - cls * per_cls;
+    const int cls = wino_div(bx, s.m_cls), brem = bx - cls * per_cls;
     const int py = ss == 2 ? cls >> 1 : 0, px = ss == 2 ? cls & 1 : 0;
-    const int tyb = wino_div(brem, s.blk_x, s.m_blkx);
+    const int tyb = wino_div(brem, s.m_blkx);
     const int ty0 = tyb * (TR * WN), tx0 = (brem - tyb * s.blk_x) * TC;
     const int b0 = by * WM;
-    const int n = wino_div(bz, a.split, s.m_split), ksplit = bz - n * a.split;
+    const int n = wino_div(bz, s.m_split), ksplit = bz - n * a.split;
     const int HWi = a.H * a.W;
 
     const int nchunks_all = a.Cin / KC;

@@ -13,8 +13,7 @@ for (Cin, Cout, H, W, dil) in ((256, 256, 54, 96, 1), (512, 512, 27, 48, 1), (12
     buf = torch.zeros(4096, 8, dtype=torch.int64, device="cuda")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     lib.dvc_debug_conv_trace(ctypes.c_void_p(buf.data_ptr()))
-    for _ in range(5): ops.conv2d_winograd(x, u, None, dil=dil)
-    buf.zero_(); torch.cuda.synchronize()
+    for _ in range(200): ops.conv2d_winograd(x, u, None, dil=dil)
     e0.record(); ops.conv2d_winograd(x, u, None, dil=dil); e1.record(); torch.cuda.synchronize()
     lib.dvc_debug_conv_trace(None)
     b = buf.cpu().double()
