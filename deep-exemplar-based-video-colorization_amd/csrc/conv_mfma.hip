@@ -377,6 +377,9 @@ extern "C" int dvc_winograd_pack_weight(const float* w, int32_t Cout, int32_t Ci
     return 0;
 }
 
+// workgroup shapes (cfg / 4): channels = 32 wm, tile blocks = wn, input channels per LDS chunk = kc, workgroups resident per CU
+static const struct { int wm, wn, kc, per_cu; } kWinoShapes[3] = {{4, 1, 4, 1}, {2, 2, 8, 1}, {2, 1, 4, 2}};
+
 // The plan of a Winograd launch: workgroup shape m, tile-block shape TR x (32/TR), split S over input-channel chunks.
 // Cost in MFMA-times per SIMD: rounds of workgroups x (chunks x MFMAs per chunk + a per-workgroup prologue/epilogue) + a
 // reduce launch.  A pure function of the descriptor and the workspace size (dvc_conv2d_winograd_split exposes S).
@@ -388,9 +391,9 @@ static void wino_plan(const DvcConvDesc* d, int OH, int OW, bool have_workspace,
     static const int kTR[4] = {1, 2, 4, 8};
     int best_m = -1, best_tr = 1, best_S = 1;
     double best_cost = 1e30;
-    const int shape_cfg = d->cfg >= 0 ? (d->cfg & 7) : -1;
-    for (int m = 0; m < 2; ++m) {
-        const int wm = m == 0 ? 4 : 2, wn = m == 0 ? 1 : 2, kc = m == 0 ? 4 : 8;
+    const int shape_cfg = d->cfg >= 0 ? d->cfg : -1;
+    for (int m = 0; m < 3; ++m) {
+        const int wm = kWinoShapes[m].wm, wn = kWinoShapes[m].wn, kc = kWinoShapes[m].kc;
         if (d->Cout % (32 * wm) != 0) continue;
         if (shape_cfg >= 0 && shape_cfg / 4 != m) continue;
         const int nch = d->Cin / kc;
@@ -405,9 +408,14 @@ static void wino_plan(const DvcConvDesc* d, int OH, int OW, bool have_workspace,
                               (size_t)S * d->Cout * OH * OW * sizeof(float) > workspace_bytes)) continue;
                 const int cps = cdiv(nch, S);
                 if (cdiv(nch, cps) != S) continue;
-                const double rounds = (double)cdivl(wgs * S, ncu);
-                double cost = rounds * (cps * (kc / 2) * 16.0 + 160.0) + (S > 1 ? 200.0 : 0.0);
+                const double rounds = (double)cdivl(wgs * S, (long)ncu * kWinoShapes[m].per_cu);
+                // (per-workgroup prologue / epilogue: partly hidden behind the sibling workgroup where two share a CU)
+                double cost = rounds * (cps * (kc / 2) * 16.0 + (kWinoShapes[m].per_cu == 2 ? 130.0 : 160.0)) + (S > 1 ? 200.0 : 0.0);
                 cost *= 1.0 + 0.02 * ti;     // wider tile rows store better
+                // tile slots that hang over the edge of the image are computed all the same, and every extra workgroup
+                // streams its filter slice again: e.g. 1x32-tile blocks on a 7x12-tile map (13x24 outputs) are 37 % full
+                const double fill = (double)TY * TX / ((double)cdiv(TY, tr * wn) * (tr * wn) * cdiv(TX, 32 / tr) * (32 / tr));
+                cost *= 1.0 + 0.3 * (1.0 - fill);
                 if (cost < best_cost) { best_cost = cost; best_m = m; best_tr = tr; best_S = S; }
             }
         }
@@ -437,7 +445,7 @@ extern "C" int dvc_conv2d_winograd_split(const DvcConvDesc* d, size_t workspace_
     wino_plan(d, OH, OW, workspace_bytes > 0, workspace_bytes, &m, &tr, &S);
     DVC_REQUIRE(m >= 0, "dvc_conv2d_winograd_split: no configuration for cfg %d / split_k %d on this layer", d->cfg, d->split_k);
     // (the launch recomputes the split from the chunk count: same arithmetic as dvc_conv2d_winograd)
-    const int kc = m == 0 ? 4 : 8, nch = d->Cin / kc;
+    const int kc = kWinoShapes[m].kc, nch = d->Cin / kc;
     *split = cdiv(nch, cdiv(nch, S));
     return 0;
 }
@@ -483,7 +491,7 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
     int best_m = -1, best_tr = 1, best_S = 1;
     wino_plan(d, OH, OW, workspace != nullptr, workspace_bytes, &best_m, &best_tr, &best_S);
     DVC_REQUIRE(best_m >= 0, "dvc_conv2d_winograd: no configuration for cfg %d / split_k %d on this layer", d->cfg, d->split_k);
-    const int wm = best_m == 0 ? 4 : 2, wn = best_m == 0 ? 1 : 2, kc = best_m == 0 ? 4 : 8;
+    const int wm = kWinoShapes[best_m].wm, wn = kWinoShapes[best_m].wn, kc = kWinoShapes[best_m].kc;
     const int nch = d->Cin / kc;
     s.blk_y = cdiv(TY, best_tr * wn);
     s.blk_x = cdiv(TX, 32 / best_tr);
@@ -523,7 +531,8 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
         s.m_split = wino_magic(a.split);
         dim3 grid((unsigned)(s.gx * s.gy * s.gz));      // 1-D: the kernel maps it XCD-aware onto (gx, gy, gz)
         if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
-        else conv_wino_launch_m2(best_tr, grid, st, s);
+        else if (best_m == 1) conv_wino_launch_m2(best_tr, grid, st, s);
+        else conv_wino_launch_m1(best_tr, grid, st, s);
         DVC_CHECK_LAUNCH("dvc_conv2d_winograd");
         if (a.split > 1 && !(d->flags & DVC_CONV_DEFER_REDUCE)) {
             const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)NB * per_img) % 4 == 0);

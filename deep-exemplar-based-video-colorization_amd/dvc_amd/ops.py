@@ -286,7 +286,7 @@ def _wino_rule(N, Cin, Cout, OH, OW, dil):
     # measured on the MI355X (profiles/r02_conv_wino_probe.txt): Winograd wins wherever the layer has enough 2x2 tiles
     # to fill the chip after the split over input channels; the 13x24 VGG block-5 layers stay on the direct engine
     # (per image, never a function of the batch size: a batch must run the kernels its images would run alone)
-    return OH * OW >= 27 * 48
+    return OH * OW >= 13 * 24
 
 
 def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1, act=ACT_NONE, act_slope=0.0,

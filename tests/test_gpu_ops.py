@@ -239,7 +239,8 @@ def test_winograd_pack_weight(ops):
 
 
 @pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
-@pytest.mark.parametrize("cfg,split_k", [(-1, 0), (0, 1), (1, 2), (2, 1), (3, 3), (4, 1), (5, 2), (6, 0), (7, 1)])
+@pytest.mark.parametrize("cfg,split_k", [(-1, 0), (0, 1), (1, 2), (2, 1), (3, 3), (4, 1), (5, 2), (6, 0), (7, 1),
+                                         (8, 1), (9, 2), (10, 0), (11, 3)])
 def test_conv2d_winograd(ops, case, cfg, split_k):
     """Winograd F(2x2,3x3) path (every tile-block shape x both workgroup shapes, with and without the split over input
     channels): the fp64 reference at a tolerance ~2.5x the direct engine's (the transform's known rounding),
@@ -248,7 +249,7 @@ def test_conv2d_winograd(ops, case, cfg, split_k):
     shape = cfg
     if shape >= 0 and shape // 4 == 0 and Cout % 128:
         pytest.skip("Cout not a multiple of the 128-channel workgroup shape")
-    if split_k > 1 and split_k > (Cin // (4 if 0 <= shape < 4 else 8)) // 2:
+    if split_k > 1 and split_k > (Cin // (8 if 4 <= shape < 8 else 4)) // 2:
         pytest.skip("fewer than two chunks per split")
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
     x = torch.randn(N, Cin, H, W, generator=g)

@@ -34,7 +34,7 @@ def main():
         wp, up_ = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
         cands = {"direct": lambda: ops.conv2d(x, wp, b, dil=dil, pad=dil, in_up=up, act=ops.ACT_RELU)}
         cands["wino auto"] = lambda: ops.conv2d_winograd(x, up_, b, dil=dil, in_up=up, act=ops.ACT_RELU)
-        for cfg in range(8):
+        for cfg in range(12):
             if cfg < 4 and Cout % 128:
                 continue
             for S in (1, 2, 3, 4, 5, 6, 8):
