@@ -208,6 +208,9 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clock-warmup-s", type=float, default=0.5,
+                    help="seconds of untimed load (the warm-up frames, repeated) before the W warm-up steps, so that the "
+                         "timed region does not start on a ramping GPU clock; 0 disables")
     ap.add_argument("--hw", default="216x384",
                     help="frame size HxW; the default is BASELINE configs[1] (the metric's configuration), "
                          "432x768 is configs[3] (information only: no CPU baseline, traffic not re-measured)")
@@ -225,6 +228,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # The host side of the GPU legs (synthesising the frames, issuing ~150 launches per frame from one thread) must not be
+    # starved by its own helper threads: the GPU boxes expose 256 hardware threads under a 16-CPU cgroup quota, and an ATen
+    # pool sized for the mask burns the quota — the launch thread then gets throttled in the middle of the timed region
+    # (seen as a 380 vs 415 frames/s difference between otherwise identical runs).  cpu_baseline() sets its own counts.
+    torch.set_num_threads(max(1, min(16, host_cpus()[0] // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # launched by torch.distributed.run
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     if args.gpus < 1:
@@ -290,6 +298,17 @@ def main():
         ab, _ = cc.frame(frames[i], last)
         return torch.cat((frames[i][:, 0:1], ab), dim=1)      # test.py:96
 
+    # clock warm-up (untimed, before the W warm-up steps): a GPU that has just been handed to this process takes a few
+    # hundred milliseconds of load to reach its sustained clocks, and W x 2.5 ms is far less — without this the first
+    # frames of a short timed region run on a ramping clock (measured: 370 frames/s at --steps 30 against 411 at --steps 60
+    # in otherwise identical runs).  Same frames, same kernels as the warm-up steps; results discarded.
+    if Wm > 0:
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < args.clock_warmup_s:
+            lw = torch.zeros(1, 3, H, W, device=device)
+            for i in range(Wm):
+                lw = step(i, lw)
+            torch.cuda.synchronize()
     for i in range(Wm):
         last = step(i, last)
     if args.lookahead > 0:
@@ -400,7 +419,7 @@ def main():
                        "bf16 MFMA candidate filter + exact fp32 re-scoring (configs[4])",
                        "exemplar_side": "recomputed per frame" if args.no_exemplar_cache else "cached per clip",
                        "conv_algorithm": {"auto": "Winograd F(2x2,3x3) on the fp32 matrix cores where ops.winograd_selected "
-                                                  "picks it (3x3 stride-1 layers with >= 27x48 outputs), direct "
+                                                  "picks it (3x3 stride-1 layers with >= 13x24 outputs), direct "
                                                   "implicit GEMM elsewhere; fp32 throughout",
                                           "winograd": "Winograd F(2x2,3x3) on every eligible 3x3 layer",
                                           "direct": "direct implicit GEMM everywhere"}[ops.conv_algo()],

@@ -283,8 +283,8 @@ def winograd_selected(N, Cin, H, W, Cout, *, ksize=3, stride=1, dil=1, pad=1, in
 
 
 def _wino_rule(N, Cin, Cout, OH, OW, dil):
-    # measured on the MI355X (profiles/r02_conv_wino_probe.txt): Winograd wins wherever the layer has enough 2x2 tiles
-    # to fill the chip after the split over input channels; the 13x24 VGG block-5 layers stay on the direct engine
+    # measured on the MI355X (profiles/r02_conv_algo_sweep.txt): with the two-workgroups-per-CU shape Winograd is faster than
+    # or level with the direct engine on every eligible layer of the network down to the 13x24 feature maps
     # (per image, never a function of the batch size: a batch must run the kernels its images would run alone)
     return OH * OW >= 13 * 24
 
