@@ -21,8 +21,26 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+# The launch thread issues ~150 kernels per frame and is within 10-15 % of being the bottleneck of the clip driver
+# (tools/host_issue_probe.py: 2.1 ms of host time per 2.4 ms frame), so the per-call plumbing uses torch's raw accessors:
+# torch.cuda.current_stream() builds a Stream object through four Python frames (3 us, called once or twice per launch).
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _current_device():
+    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
+
+
+def _stream_handle():
+    """The current HIP stream of the current device as an integer handle."""
+    if _raw_stream is not None:
+        return _raw_stream(_current_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_stream_handle())
 
 
 def _need(t, name):
@@ -34,11 +52,11 @@ def _need(t, name):
         raise RuntimeError(f"dvc_amd: `{name}` must be float32 (got {t.dtype})")
     if not t.is_contiguous():
         raise RuntimeError(f"dvc_amd: `{name}` must be contiguous")
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != _current_device():
         # libdvc_hip launches on the CURRENT device's current stream and never calls hipSetDevice:
         # one process per GPU (torch.cuda.set_device(LOCAL_RANK)) is the supported mode
         raise RuntimeError(f"dvc_amd: `{name}` lives on {t.device} but the current device is cuda:"
-                           f"{torch.cuda.current_device()}; call torch.cuda.set_device / use torch.cuda.device(...)")
+                           f"{_current_device()}; call torch.cuda.set_device / use torch.cuda.device(...)")
 
 
 conv_record = None   # set to a list to log every conv2d launch (tools/tune_conv.py)
@@ -527,7 +545,7 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes, tag="corr"):
-    key = (tag, device.index, torch.cuda.current_stream().cuda_stream)
+    key = (tag, device.index, _stream_handle())
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
