@@ -22,7 +22,8 @@
 // issue and MFMA->VALU wait states: that kernel was built first and measured with parts of its K-step removed
 // (profiles/r02_conv_wino_one_wave_dbg.txt: 29 % of a 24-GFLOP layer's time was such in-loop overhead).  Here the 16
 // positions are shared by a PAIR of waves: wave half ph owns rows i = 2 ph, 2 ph + 1 (8 positions, 128 accumulator
-// registers), a workgroup is 8 waves, two per SIMD, and the hardware interleaves them (24-46 % faster on every layer of
+// registers), a CU holds 8 such waves, two per SIMD — one 8-wave workgroup or two 4-wave ones (conv_wino_m1.hip), possibly of
+// different launches — and the hardware interleaves them (24-46 % faster on every layer of
 // the network, profiles/r02_conv_algo_sweep.txt).  What the split costs:
 //   * the input transform V = B^T d B of rows 2 ph, 2 ph + 1 needs three of the four patch rows (48 instead of 64
 //     bytes of LDS per lane and K-step, for half the MFMAs) and half the arithmetic: (B^T d) rows 2 ph, 2 ph + 1 and
@@ -36,7 +37,8 @@
 // Dilation 2 (ColorVidNet conv5/conv6): the four pixel-parity classes of the output are four independent dilation-1
 // problems on the sub-sampled grids x[2u + py][2v + px]; a workgroup works inside one class (`ss` = 2), only the
 // DMA address plan and the output index know about it.
-// Work decomposition: workgroup = 32*WM channels x WN blocks of 32 tiles (TR x 32/TR tiles each, stacked vertically);
+// Work decomposition: workgroup = 32*WM channels x WN blocks of 32 tiles (TR x 32/TR tiles each, stacked vertically), i.e.
+// WM*WN wave pairs; the shapes in use are 4x1 and 2x2 (8 waves, 111 KB of LDS) and 2x1 (4 waves, 64 KB: two per CU);
 // layers that cannot fill the chip are split over input-channel chunks (blockIdx.z), partial OUTPUT tiles (the
 // inverse transform is linear) go to the split-K workspace and conv_splitk_reduce_kernel adds them in a fixed order.
 #pragma once

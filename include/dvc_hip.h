@@ -111,7 +111,8 @@ int dvc_conv2d(const DvcConvDesc* d,
  * the reference's cudnn.benchmark = True, test.py:140).  Requirements: ksize 3, stride 1, dil 1|2 with pad == dil,
  * Cin % 8 == 0, Cout % 64 == 0, in_prelu == 0.  Descriptor fields as for dvc_conv2d except
  *   cfg      -1 = automatic | tile-block shape (0: 1x32, 1: 2x16, 2: 4x8, 3: 8x4 tiles) + 4 * workgroup shape
- *            (0: 128 channels x 32 tiles, 1: 64 channels x 64 tiles)
+ *            (0: 128 channels x 32 tiles, 1: 64 channels x 64 tiles — 8 waves, one workgroup per CU; 2: 64 channels x
+ *            32 tiles — 4 waves and 64 KB of LDS, two workgroups per CU)
  *   split_k  0 = automatic | 1..8 = split over input-channel chunks (needs the workspace, as dvc_conv2d)
  * u_packed: the filters in the transform domain, U = G g G^T, laid out [Cout/32][Cin][4][32][4]
  * (dvc_winograd_weight_floats(Cout, Cin) floats, written by dvc_winograd_pack_weight). */
