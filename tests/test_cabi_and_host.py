@@ -152,3 +152,33 @@ def test_fma_division_by_constant_is_correctly_rounded():
             q = fma(fma(-T, q, f), y, q)
             q = fma(fma(-T, q, f), y, q)
             assert q == rn32(Fraction(f) / Fraction(T)), (T, f)
+
+
+def test_winograd_plan_is_a_pure_function_of_the_layer_not_of_the_batch():
+    """Host logic, no GPU: the split over input channels the Winograd launcher would use (dvc_conv2d_winograd_split) and the
+    engine choice (ops.winograd_selected) must not depend on the batch size — the clip driver's batched front ends and the
+    bit-identical-batch tests rest on it — and the split is one the kernel supports."""
+    import ctypes
+    from dvc_amd import _lib, ops
+    lib = _lib.load()
+    ws = 64 << 20
+    layers = [(256, 256, 54, 96, 1, 1), (512, 512, 27, 48, 1, 1), (512, 512, 27, 48, 2, 1), (128, 128, 216, 384, 1, 1),
+              (64, 64, 216, 384, 1, 1), (512, 512, 13, 24, 1, 1), (256, 64, 13, 24, 1, 2), (128, 256, 54, 96, 1, 1)]
+    for (ci, co, H, W, dil, up) in layers:
+        got = []
+        for N in (1, 2, 5):
+            d = _lib.DvcConvDesc(N, ci, H, W, co, 3, 1, dil, dil, 0, up, 1, 1, 0.0, 0, -1, 0, 0, 0, 0, 0)
+            sp = ctypes.c_int32(0)
+            assert lib.dvc_conv2d_winograd_split(ctypes.byref(d), ws, ctypes.byref(sp)) == 0, lib.dvc_last_error()
+            got.append(sp.value)
+            assert ops.winograd_selected(N, ci, H, W, co, dil=dil, pad=dil, in_up=up) == \
+                ops.winograd_selected(1, ci, H, W, co, dil=dil, pad=dil, in_up=up)
+        assert got[0] == got[1] == got[2] and 1 <= got[0] <= 8, (ci, co, H, W, got)
+    # without a workspace there is nothing to split into
+    d = _lib.DvcConvDesc(1, 256, 54, 96, 256, 3, 1, 1, 1, 0, 1, 1, 1, 0.0, 0, -1, 0, 0, 0, 0, 0)
+    sp = ctypes.c_int32(0)
+    assert lib.dvc_conv2d_winograd_split(ctypes.byref(d), 0, ctypes.byref(sp)) == 0 and sp.value == 1
+    # a layer the kernel does not take is refused with a message, not planned
+    bad = _lib.DvcConvDesc(1, 3, 54, 96, 64, 3, 1, 1, 1, 0, 1, 1, 1, 0.0, 0, -1, 0, 0, 0, 0, 0)
+    assert lib.dvc_conv2d_winograd_split(ctypes.byref(bad), ws, ctypes.byref(sp)) != 0
+    assert b"Cin" in lib.dvc_last_error()
