@@ -6,6 +6,15 @@
 
 #include "dvc_hip.h"
 
+// Diagnostics (timeline stamps, timing-experiment variants that compute WRONG results) exist only in a -DDVC_DEBUG build
+// (`make DEBUG=1` -> dvc_amd/libdvc_hip_debug.so, used by tools/); the production library carries neither the hooks nor
+// the process-global state behind them.
+#ifdef DVC_DEBUG
+constexpr bool kDvcDebug = true;
+#else
+constexpr bool kDvcDebug = false;
+#endif
+
 char* dvc_err_buf();  // thread-local, 512 bytes
 
 static inline int dvc_fail(const char* fmt, ...) {

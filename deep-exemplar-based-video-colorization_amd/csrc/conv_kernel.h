@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(RM * RN, TW, DIL, GEN,
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     long long* dbgp = nullptr;
-    if (DMA && a.dbg_buf && tid == 0) {
+    if (kDvcDebug && DMA && a.dbg_buf && tid == 0) {
         dbgp = a.dbg_buf + 4L * (blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z));
         dbgp[0] = __builtin_amdgcn_s_memtime();
         dbgp[2] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(RM * RN, TW, DIL, GEN,
 
     // LDS-DMA staging of chunk `ci` (DMA variants): every lane supplies its own global address, the LDS
     // destination is wave-uniform base + lane * size.
-    const bool dbg_nox = a.dbg == 1 || a.dbg == 2, dbg_now = a.dbg == 1 || a.dbg == 3;
+    const bool dbg_nox = kDvcDebug && (a.dbg == 1 || a.dbg == 2), dbg_now = kDvcDebug && (a.dbg == 1 || a.dbg == 3);
     auto issue_dma = [&](int ci, float* xs, float* ws) {
         const float* xc = xn + (long)ci * CK * HWi;
         const float* wc = a.w + (long)ci * CK * KK * a.Cout;
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(RM * RN, TW, DIL, GEN,
         if (ci + 1 < nchunks) chunk(ci + 1, xsb1, wsb1, xsb0, wsb0);
     }
 
-    if (dbgp) dbgp[1] = __builtin_amdgcn_s_memtime();
+    if (kDvcDebug && dbgp) dbgp[1] = __builtin_amdgcn_s_memtime();
     // ---- epilogue
     if (a.split > 1) {  // split-K: raw partial sums; bias / residual / activation happen in the reduce kernel
         const long OHW = (long)a.OH * a.OW;

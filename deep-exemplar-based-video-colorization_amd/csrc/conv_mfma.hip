@@ -86,10 +86,15 @@ static int conv_num_cus() {
     return n;
 }
 
+#ifdef DVC_DEBUG
 static int g_conv_dbg = 0;
 static long long* g_conv_dbg_buf = nullptr;
 extern "C" void dvc_debug_conv_trace(long long* buf) { g_conv_dbg_buf = buf; }   // diagnostics (dvc_hip.h, last section)
 extern "C" void dvc_debug_conv_variant(int v) { g_conv_dbg = v; }
+#else
+static constexpr int g_conv_dbg = 0;
+static constexpr long long* g_conv_dbg_buf = nullptr;
+#endif
 
 // One launch (plus its reduce / fixup) for the d->N images at x / y.  The PLAN — tile configuration, split over input
 // channels, stream-K ranges — is always the single-image plan: an image's result never depends on what else is in the
@@ -435,8 +440,25 @@ static int wino_check_desc(const DvcConvDesc* d) {
     return 0;
 }
 
-extern "C" int dvc_conv2d_winograd_split(const DvcConvDesc* d, size_t workspace_bytes, int32_t* split) {
-    DVC_REQUIRE(d && split, "dvc_conv2d_winograd_split: null argument");
+// Images one Winograd launch covers: all of them, unless the workspace holds the partial outputs of fewer at this
+// (single-image) split, or the 1-D grid would pass the 65535 workgroups the kernel's 16-bit reciprocal index decode
+// handles.  -1: a single image already needs more workgroups than that.
+static int wino_images_per_launch(const DvcConvDesc* d, int OH, int OW, int m, int tr, int split, size_t workspace_bytes) {
+    const int ss = d->dil, wm = kWinoShapes[m].wm, wn = kWinoShapes[m].wn;
+    const int TY = cdiv(cdiv(OH, ss), 2), TX = cdiv(cdiv(OW, ss), 2);
+    const long gx = (long)ss * ss * cdiv(TY, tr * wn) * cdiv(TX, 32 / tr), gy = d->Cout / (32 * wm);
+    const size_t per_img = (size_t)d->Cout * OH * OW * sizeof(float);
+    long group = d->N;
+    if (split > 1 && (size_t)d->N * split * per_img > workspace_bytes) group = (long)(workspace_bytes / ((size_t)split * per_img));
+    const long per_image = gx * gy * split;
+    if (per_image >= 65536) return -1;
+    if (group * per_image >= 65536) group = 65535 / per_image;
+    return (int)group;
+}
+
+extern "C" int dvc_conv2d_winograd_split(const DvcConvDesc* d, size_t workspace_bytes, int32_t* split,
+                                         int32_t* images_per_launch) {
+    DVC_REQUIRE(d && split && images_per_launch, "dvc_conv2d_winograd_split: null argument");
     if (int rc = wino_check_desc(d)) return rc;
     int32_t OH, OW;
     dvc_conv2d_out_hw(d, &OH, &OW);
@@ -447,6 +469,7 @@ extern "C" int dvc_conv2d_winograd_split(const DvcConvDesc* d, size_t workspace_
     // (the launch recomputes the split from the chunk count: same arithmetic as dvc_conv2d_winograd)
     const int kc = kWinoShapes[m].kc, nch = d->Cin / kc;
     *split = cdiv(nch, cdiv(nch, S));
+    *images_per_launch = wino_images_per_launch(d, OH, OW, m, tr, *split, workspace_bytes);
     return 0;
 }
 
@@ -503,15 +526,10 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
     hipStream_t st = (hipStream_t)stream;
     const long OHW = (long)OH * OW, per_img = (long)d->Cout * OHW;
     // images per launch: all of them, unless the workspace holds the partial outputs of fewer at this (single-image) split
-    int group = d->N;
-    if (a.split > 1 && (size_t)d->N * a.split * per_img * sizeof(float) > workspace_bytes)
-        group = (int)(workspace_bytes / ((size_t)a.split * per_img * sizeof(float)));
+    const int group = wino_images_per_launch(d, OH, OW, best_m, best_tr, a.split, workspace_bytes);
+    DVC_REQUIRE(group >= 0, "dvc_conv2d_winograd: %ld workgroups per image (feature map too large for this path)",
+                (long)s.gx * s.gy * a.split);
     DVC_REQUIRE(group > 0, "dvc_conv2d_winograd: split-K workspace too small for one image");
-    {   // the kernel decodes its workgroup index with 16-bit reciprocal multiplications: at most 65535 workgroups per launch
-        const long per_image = (long)s.gx * s.gy * a.split;
-        DVC_REQUIRE(per_image < 65536, "dvc_conv2d_winograd: %ld workgroups per image (feature map too large for this path)", per_image);
-        if ((long)group * per_image >= 65536) group = (int)(65535 / per_image);
-    }
     DVC_REQUIRE(!(d->flags & DVC_CONV_DEFER_REDUCE) || a.split == 1 || group >= d->N,
                 "dvc_conv2d_winograd: DVC_CONV_DEFER_REDUCE needs a workspace that holds the partial sums of the whole batch");
     DVC_REQUIRE(!(d->flags & DVC_CONV_DEFER_REDUCE) || a.split == 1 || !residual,

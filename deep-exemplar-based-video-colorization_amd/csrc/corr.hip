@@ -625,6 +625,7 @@ extern "C" size_t dvc_corr_workspace_bytes(int32_t B, int32_t P) {
 
 // debug hook (not part of the public header): the next dvc_corr_fwd launches record per-tile s_memtime
 // stamps of wave 0 of every workgroup into `buf` ([workgroups][max_tiles][4]); pass NULL to switch off.
+#ifdef DVC_DEBUG
 static long long* g_corr_dbg = nullptr;
 static int g_corr_dbg_tiles = 0;
 static int g_corr_dbg_variant = 0;
@@ -633,6 +634,10 @@ extern "C" void dvc_debug_corr_timeline(long long* buf, int max_tiles) {
     g_corr_dbg_tiles = max_tiles;
 }
 extern "C" void dvc_debug_corr_variant(int v) { g_corr_dbg_variant = v; }
+#else
+static constexpr long long* g_corr_dbg = nullptr;
+static constexpr int g_corr_dbg_tiles = 0, g_corr_dbg_variant = 0;
+#endif
 
 extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* blab, float temperature,
                             float wta_scale, int32_t B, int32_t C, int32_t h, int32_t w, float* y_small,
@@ -686,7 +691,9 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
             else hipLaunchKernelGGL((corr_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
         } else {
             if (vec4 && soft) hipLaunchKernelGGL((corr_fwd_kernel<false, true, true>), grid, dim3(256), 0, s, a);
+#ifdef DVC_DEBUG
             else if (vec4 && (a.dbg || a.dbg_variant)) hipLaunchKernelGGL((corr_fwd_kernel<false, true, false, true>), grid, dim3(256), 0, s, a);
+#endif
             else if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
             else if (soft) hipLaunchKernelGGL((corr_fwd_kernel<false, false, true>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((corr_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);

@@ -12,28 +12,40 @@
 
 #include <cmath>
 
-// l_i = sum_j exp(fl32(F_ij / T) - m_i),  m_i = fl32(sim_i / T): ATen's softmax arithmetic (true division, exp of the
-// difference to the row maximum), one workgroup per row.
-__global__ __launch_bounds__(256) void corr_bwd_rowsum_kernel(const float* __restrict__ F, const float* __restrict__ sim,
-                                                              float T, int P, float* __restrict__ l_out) {
+// m_i = max_j fl32(F_ij / T),  l_i = sum_j exp(fl32(F_ij / T) - m_i): ATen's softmax arithmetic (true division, exp of the
+// difference to the row maximum), one workgroup per row.  The maximum is taken over the block as RECOMPUTED here (the
+// forward kernel's similarity comes from another summation order and need not bound it: at T <= 1e-7 an excess of one
+// ulp would overflow the exponential).
+__global__ __launch_bounds__(256) void corr_bwd_rowstat_kernel(const float* __restrict__ F, float T, int P,
+                                                               float* __restrict__ m_out, float* __restrict__ l_out) {
     __shared__ float red[4];
     const int row = blockIdx.x;
     const float* f = F + (long)row * P;
-    const float m = sim[row] / T;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < P; j += 256) mx = fmaxf(mx, f[j] / T);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
     float s = 0.f;
     for (int j = threadIdx.x; j < P; j += 256) s += expf(f[j] / T - m);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) l_out[row] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        m_out[row] = m;
+        l_out[row] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
 }
 
 // dS tile 64 rows x 64 columns: computed once, written row-major (coalesced along j) and, through an LDS transpose,
 // column-major (coalesced along i).
 __global__ __launch_bounds__(256) void corr_bwd_ds_kernel(const float* __restrict__ F, const float* __restrict__ blab,
                                                           const float* __restrict__ gy, const float* __restrict__ y,
-                                                          const float* __restrict__ sim, const float* __restrict__ gsim,
+                                                          const float* __restrict__ rowmax, const float* __restrict__ gsim,
                                                           const int* __restrict__ amax, const float* __restrict__ lsum,
                                                           float T, int rows, int P, long cs, int ldt,
                                                           float* __restrict__ dS, float* __restrict__ dST) {
@@ -55,8 +67,7 @@ __global__ __launch_bounds__(256) void corr_bwd_ds_kernel(const float* __restric
         if (i < rows && jok) {
             const float g0 = gy[i], g1 = gy[cs + i], g2 = gy[2 * cs + i];
             const float delta = g0 * y[i] + g1 * y[cs + i] + g2 * y[2 * cs + i];
-            const float m = sim[i] / T;
-            const float p = expf(F[(long)i * P + j] / T - m) / lsum[i];
+            const float p = expf(F[(long)i * P + j] / T - rowmax[i]) / lsum[i];
             v = p * ((g0 * b0 + g1 * b1 + g2 * b2) - delta) / T;
             if (gsim && amax[i] == j) v += gsim[i];
             dS[(long)i * P + j] = v;
@@ -75,16 +86,19 @@ __global__ __launch_bounds__(256) void corr_bwd_ds_kernel(const float* __restric
 
 extern "C" int dvc_corr_softmax_bwd(const float* f_blk, const float* blab, const float* gy, const float* y,
                                     const float* sim, const float* gsim, const int32_t* argmax, float temperature,
-                                    int32_t rows, int32_t P, int64_t chan_stride, int32_t ld_t, float* lsum_scratch,
+                                    int32_t rows, int32_t P, int64_t chan_stride, int32_t ld_t, float* rowstat_scratch,
                                     float* dS, float* dST, dvcStream stream) {
-    DVC_REQUIRE(f_blk && blab && gy && y && sim && lsum_scratch && dS && dST, "dvc_corr_softmax_bwd: null argument");
+    DVC_REQUIRE(f_blk && blab && gy && y && rowstat_scratch && dS && dST, "dvc_corr_softmax_bwd: null argument");
+    (void)sim;
+    float* rowmax = rowstat_scratch;
+    float* lsum_scratch = rowstat_scratch + ld_t;
     DVC_REQUIRE(rows > 0 && P > 0 && ld_t >= rows, "dvc_corr_softmax_bwd: bad shape");
     DVC_REQUIRE(temperature > 0.f && std::isfinite(temperature), "dvc_corr_softmax_bwd: temperature must be > 0");
     DVC_REQUIRE((gsim == nullptr) == (argmax == nullptr), "dvc_corr_softmax_bwd: gsim and argmax come together");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(corr_bwd_rowsum_kernel, dim3(rows), dim3(256), 0, s, f_blk, sim, temperature, P, lsum_scratch);
+    hipLaunchKernelGGL(corr_bwd_rowstat_kernel, dim3(rows), dim3(256), 0, s, f_blk, temperature, P, rowmax, lsum_scratch);
     DVC_CHECK_LAUNCH("dvc_corr_softmax_bwd(rowsum)");
-    hipLaunchKernelGGL(corr_bwd_ds_kernel, dim3(cdiv(P, 64), cdiv(ld_t, 64)), dim3(256), 0, s, f_blk, blab, gy, y, sim, gsim,
+    hipLaunchKernelGGL(corr_bwd_ds_kernel, dim3(cdiv(P, 64), cdiv(ld_t, 64)), dim3(256), 0, s, f_blk, blab, gy, y, rowmax, gsim,
                        argmax, lsum_scratch, temperature, rows, P, (long)chan_stride, ld_t, dS, dST);
     DVC_CHECK_LAUNCH("dvc_corr_softmax_bwd(dS)");
     return 0;

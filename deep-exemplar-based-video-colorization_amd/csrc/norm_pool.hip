@@ -37,35 +37,51 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 // InstanceNorm statistics: one workgroup per (n,c) plane, ONE pass: sum and sum of squares accumulated in
 // fp64 (fp32 inputs are exact in fp64 and 53-bit accumulation leaves > 25 bits after the E[x^2]-E[x]^2
 // cancellation for any realistic mean/std ratio; ATen's CPU statistics also accumulate in double).
-// Works for any block size that is a multiple of 64 up to 1024; every thread returns the plane's
+// The summation tree is that of 1024 VIRTUAL threads whatever the block size (256, 512 or 1024): virtual thread v sums the
+// float4 pieces v, v + 1024, ... in order, 64 consecutive virtual threads are combined by the wave butterfly, the 16 wave
+// sums are added in ascending order — a real thread carries 1024 / blockDim.x virtual ones in separate accumulators.  The
+// statistics of a plane are therefore bit-identical from every kernel that calls this (dvc_instnorm_stats, dvc_instnorm_apply
+// and dvc_instnorm_apply_partials launch different block sizes).  Every thread returns the plane's
 // (scale, shift) = (rstd * chan_scale, -mean * scale).
 __device__ __forceinline__ void plane_stats(const float* __restrict__ xp, int HW, float eps, float cs,
                                             double* red /* [36] */, float* sc_out, float* sh_out) {
+    constexpr int VT = 1024;
     const int tid = threadIdx.x, nt = blockDim.x;
-    double s = 0.0, q = 0.0;
+    const int nv = VT / nt;        // virtual threads per real thread: 1, 2 or 4
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
     const int HW4 = ((reinterpret_cast<uintptr_t>(xp) & 15) == 0) ? (HW & ~3) : 0;
-    for (int i = tid * 4; i < HW4; i += nt * 4) {
-        float4 v = *reinterpret_cast<const float4*>(xp + i);
-        double a = v.x, b = v.y, cc = v.z, d = v.w;
-        s += (a + b) + (cc + d);
-        q += (a * a + b * b) + (cc * cc + d * d);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < nv) {
+            const int v = tid + k * nt;
+            for (int i = v * 4; i < HW4; i += VT * 4) {
+                float4 x4 = *reinterpret_cast<const float4*>(xp + i);
+                double a = x4.x, b = x4.y, cc = x4.z, d = x4.w;
+                s[k] += (a + b) + (cc + d);
+                q[k] += (a * a + b * b) + (cc * cc + d * d);
+            }
+            for (int i = HW4 + v; i < HW; i += VT) {
+                double a = xp[i];
+                s[k] += a;
+                q[k] += a * a;
+            }
+        }
     }
-    for (int i = HW4 + tid; i < HW; i += nt) {
-        double a = xp[i];
-        s += a;
-        q += a * a;
-    }
-    s = wave_sum_d(s);
-    q = wave_sum_d(q);
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-    if (lane == 0) {
-        red[wave] = s;
-        red[16 + wave] = q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < nv) {
+            const double sk = wave_sum_d(s[k]), qk = wave_sum_d(q[k]);
+            if (lane == 0) {
+                red[wave + k * nw] = sk;
+                red[16 + wave + k * nw] = qk;
+            }
+        }
     }
     __syncthreads();
     if (tid == 0) {
         double S = 0.0, Q = 0.0;
-        for (int i = 0; i < nw; ++i) {
+        for (int i = 0; i < VT / 64; ++i) {
             S += red[i];
             Q += red[16 + i];
         }

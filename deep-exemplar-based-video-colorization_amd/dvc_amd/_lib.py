@@ -8,8 +8,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvc_hip.so")
-ABI_VERSION = 9
+# DVC_DEBUG_LIB=1 (tools/ only) loads the -DDVC_DEBUG build, the only one that carries the dvc_debug_* hooks
+DEBUG_BUILD = os.environ.get("DVC_DEBUG_LIB", "0") == "1"
+LIB_PATH = os.path.join(_HERE, "libdvc_hip_debug.so" if DEBUG_BUILD else "libdvc_hip.so")
+ABI_VERSION = 10
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -37,7 +39,8 @@ SIGNATURES = {
                                   ctypes.c_size_t, _VP]),
     "dvc_winograd_weight_floats": (ctypes.c_size_t, [c_i32, c_i32]),
     "dvc_winograd_pack_weight": (ctypes.c_int, [_VP, c_i32, c_i32, _VP, _VP]),
-    "dvc_conv2d_winograd_split": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), ctypes.c_size_t, ctypes.POINTER(c_i32)]),
+    "dvc_conv2d_winograd_split": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), ctypes.c_size_t, ctypes.POINTER(c_i32),
+                                                ctypes.POINTER(c_i32)]),
     "dvc_conv2d_winograd": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                            ctypes.c_size_t, _VP]),
     "dvc_conv1x1_small": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, _VP, _VP]),
@@ -84,7 +87,9 @@ SIGNATURES = {
                                          _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_size_t, _VP]),
     "dvc_corr_softmax_bwd": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i64, c_i32,
                                             _VP, _VP, _VP, _VP]),
-    # diagnostics for tools/ (include/dvc_hip.h, last section)
+}
+# diagnostics for tools/ (include/dvc_hip.h, last section): exported by the -DDVC_DEBUG build only
+DEBUG_SIGNATURES = {
     "dvc_debug_conv_trace": (None, [_VP]),
     "dvc_debug_conv_variant": (None, [ctypes.c_int]),
     "dvc_debug_corr_timeline": (None, [_VP, ctypes.c_int]),
@@ -101,7 +106,8 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (or `make -C csrc`). "
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (or `make -C csrc`"
+            f"{' DEBUG=1' if DEBUG_BUILD else ''}). "
             "There is no CPU fallback for the HIP path.")
     # torch ships its own ROCm runtime (libamdhip64 / libhsa-runtime64); it must be the one already
     # mapped when our library's DT_NEEDED entries are resolved, otherwise two HIP runtimes coexist in
@@ -110,7 +116,10 @@ def load():
     if torch.cuda.is_available():
         torch.cuda.init()
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    table = dict(SIGNATURES)
+    if DEBUG_BUILD:
+        table.update(DEBUG_SIGNATURES)
+    for name, (res, args) in table.items():
         fn = getattr(lib, name)  # AttributeError here == symbol missing from the .so
         fn.restype = res
         fn.argtypes = args

@@ -53,7 +53,7 @@ class _FusedCorrelation(torch.autograd.Function):
         F = torch.empty((1, R, h, w), device=dev, dtype=torch.float32)
         dS = torch.empty((1, R, h, w), device=dev, dtype=torch.float32)
         dST = torch.empty((1, P, R // 32, 32), device=dev, dtype=torch.float32)     # [P][R] as an image of R "pixels"
-        lsum = torch.empty(R, device=dev, dtype=torch.float32)
+        lsum = torch.empty(2 * R, device=dev, dtype=torch.float32)      # row maxima and row sums of the recomputed block
         for b in range(B):
             phi_img = phi[b].view(1, C, h, w)
             phi_t = phi[b].t().contiguous().view(P, 1, C)            # K-major weights of d theta = phi dS^T

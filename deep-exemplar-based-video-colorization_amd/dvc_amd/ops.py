@@ -244,10 +244,13 @@ def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_
     generation = _bump_generation(ws)
     S = 1
     if defer_reduce and residual is None and OH * OW <= 16384 and act in (ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY):
-        sp = ctypes.c_int32(0)
-        _lib.check(lib.dvc_conv2d_winograd_split(ctypes.byref(d), ws.numel(), ctypes.byref(sp)), "dvc_conv2d_winograd_split")
+        sp, ipl = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.check(lib.dvc_conv2d_winograd_split(ctypes.byref(d), ws.numel(), ctypes.byref(sp), ctypes.byref(ipl)),
+                   "dvc_conv2d_winograd_split")
         S = sp.value
-        if S > 1 and S * N * Cout * OH * OW * 4 <= ws.numel():
+        # (a batch the library would cover in several launches - workspace capacity, 65535-workgroup cap - takes the
+        # ordinary reduce: the deferred partial sums must be those of the whole batch)
+        if S > 1 and ipl.value >= N and S * N * Cout * OH * OW * 4 <= ws.numel():
             d.flags = DEFER_REDUCE
         else:
             S = 1
@@ -334,6 +337,10 @@ _TUNE_STREAMK = tuple((int(a), int(b)) for a, b in (v.split(":") for v in _os.en
 def _tune_conv(lib, d, tensors):
     """Time every (cfg, split_k) candidate for descriptor `d`; returns the fastest pair."""
     x, w_packed, bias, in_scale, in_shift, in_slope_t, act_slope_t, residual, out = tensors
+    if residual is not None and residual.data_ptr() == out.data_ptr():
+        # accumulate-in-place call (corr_autograd: d_phi += theta_blk dS): every timing launch would add the product
+        # once more into the caller's tensor — time into a scratch output, the caller's launch follows the tuning
+        out = torch.empty_like(out)
     ws = _workspace(x.device, CONV_WORKSPACE_BYTES, "conv")
     stream = _stream()
 

@@ -9,8 +9,8 @@ sequential run at the chunk boundaries (first frame of a chunk sees zeros instea
 prediction).
 
 Collectives (torch.distributed; backend "nccl" == RCCL over xGMI on ROCm, "gloo" in CPU tests):
-  * one broadcast per clip of the exemplar: IB_lab (1 MB) and, when the exemplar side is cached,
-    its products phi (256 x P fp32 = 5.3 MB at 216x384) and the pooled Lab (62 KB) from rank 0;
+  * ONE broadcast per clip of the exemplar, a single flat byte buffer from rank 0: IB_lab (1 MB) and, when the
+    exemplar side is cached, its products phi (256 x P fp32 = 5.3 MB at 216x384) and the pooled Lab (62 KB);
   * an optional all_gather of the ab predictions (663 KB/frame) when one rank needs the whole clip.
 There is no collective in the per-frame path.
 """
@@ -37,26 +37,52 @@ def broadcast_exemplar(cc, IB_lab, shape, device, src=0):
     `cc` needs: .cache_exemplar, .set_exemplar(IB_lab), .IB_lab, and — when cache_exemplar is on —
     .exemplar_cache_spec(shape) / .exemplar_cache_tensors() / .load_exemplar_cache(IB, tensors)
     (fp32 cache: phi + pooled Lab, 5.4 MB at 216x384; bf16 candidate-filter cache: phi in fp32 and bf16 +
-    pooled Lab, 8 MB).  One broadcast per tensor, rank `src` -> all, once per clip."""
+    pooled Lab, 8 MB).  ONE collective per clip: the exemplar Lab and the cache tensors travel as one flat byte
+    buffer (every tensor at a 16-byte aligned offset; bytes, because RCCL has no int16 for the bf16 bit patterns)
+    from rank `src` to all — a ring/tree broadcast pays its per-link latency once instead of three or four times."""
     world, rank = _world()
     if not (dist.is_available() and dist.is_initialized()):
         cc.set_exemplar(IB_lab)
         return
-    IB = IB_lab.contiguous() if rank == src else torch.empty(shape, device=device, dtype=torch.float32)
-    dist.broadcast(IB, src)
-    if not cc.cache_exemplar:
-        cc.set_exemplar(IB)          # every rank prepares (and re-prepares per frame) the exemplar side itself
-        return
+    spec = [(tuple(shape), torch.float32)]
+    if cc.cache_exemplar:
+        spec += [(tuple(s), dt) for s, dt in cc.exemplar_cache_spec(shape)]
+    offs, total = flat_layout(spec)
+    flat = torch.empty(total, device=device, dtype=torch.uint8)
+    views = [flat[o:o + _nbytes(s, dt)].view(dt).view(s) for o, (s, dt) in zip(offs, spec)]
     if rank == src:
-        cc.set_exemplar(IB)
-        bufs = cc.exemplar_cache_tensors()
-    else:
-        bufs = [torch.empty(s, device=device, dtype=dt) for s, dt in cc.exemplar_cache_spec(shape)]
-    for b in bufs:
-        # as raw bytes: RCCL has no int16 (the bf16 bit patterns of the candidate-filter cache)
-        dist.broadcast(b.view(torch.uint8) if b.dtype not in (torch.float32, torch.uint8) else b, src)
-    if rank != src:
-        cc.load_exemplar_cache(IB, bufs)
+        IB = IB_lab.contiguous().float()
+        src_tensors = [IB]
+        if cc.cache_exemplar:
+            cc.set_exemplar(IB)
+            src_tensors += cc.exemplar_cache_tensors()
+        for v, t in zip(views, src_tensors):
+            v.copy_(t)
+    dist.broadcast(flat, src)
+    if rank == src:
+        if not cc.cache_exemplar:
+            cc.set_exemplar(IB)
+        return
+    if not cc.cache_exemplar:
+        cc.set_exemplar(views[0])    # every rank prepares (and re-prepares per frame) the exemplar side itself
+        return
+    cc.load_exemplar_cache(views[0], views[1:])
+
+
+def _nbytes(shape, dtype):
+    n = torch.empty((), dtype=dtype).element_size()
+    for d in shape:
+        n *= int(d)
+    return n
+
+
+def flat_layout(spec):
+    """[(shape, dtype)] -> (byte offset of every tensor, total bytes): consecutive, each start rounded up to 16 bytes."""
+    offs, o = [], 0
+    for s, dt in spec:
+        offs.append(o)
+        o = (o + _nbytes(s, dt) + 15) // 16 * 16
+    return offs, o
 
 
 def colorize_clip_sharded(cc, frames_lab, IB_lab, device, gather=True, src=0):

@@ -25,9 +25,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in this header are exported. */
+#pragma GCC visibility push(default)
+
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 9
+#define DVC_ABI_VERSION 10
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -120,8 +123,10 @@ size_t dvc_winograd_weight_floats(int32_t Cout, int32_t Cin);
 /* w: [Cout][Cin][3][3] (the nn.Conv2d weight as stored in the reference's checkpoints) -> u_packed, evaluated in double
  * and rounded once.  Cout % 32 == 0. */
 int dvc_winograd_pack_weight(const float* w, int32_t Cout, int32_t Cin, float* u_packed, dvcStream stream);
-/* the split over input channels dvc_conv2d_winograd uses for this descriptor and workspace size (1 = none); a pure function */
-int dvc_conv2d_winograd_split(const DvcConvDesc* d, size_t workspace_bytes, int32_t* split);
+/* the split over input channels dvc_conv2d_winograd uses for this descriptor and workspace size (1 = none) and the number of
+ * images one launch of it covers (workspace capacity at that split, 65535-workgroup cap); a pure function.  A caller that
+ * wants DVC_CONV_DEFER_REDUCE must check images_per_launch >= d->N first. */
+int dvc_conv2d_winograd_split(const DvcConvDesc* d, size_t workspace_bytes, int32_t* split, int32_t* images_per_launch);
 int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const float* u_packed,
                         const float* bias /* may be NULL */, const float* act_slope_ptr /* device scalar or NULL */,
                         const float* residual /* or NULL */, float* y,
@@ -327,15 +332,20 @@ int dvc_cx_normalize_bwd(const float* xn, const float* norm, const float* dxn, i
  * written row-major (dS[rows][P]) and transposed (dST[P][ld_t], rows >= `rows` zero-filled) — the two K-major operands
  * of the 1x1-convolution GEMMs that follow (d phi += theta_blk dS, d theta_blk = phi dS^T).
  * gy, y: [3][.] with `chan_stride` elements between channels, already offset to the block's first query; sim, gsim,
- * argmax likewise (gsim / argmax may both be NULL: no gradient through the similarity map).  lsum_scratch: [rows]. */
+ * argmax likewise (gsim / argmax may both be NULL: no gradient through the similarity map).  The softmax is re-evaluated
+ * around the row maximum of f_blk ITSELF (the block is recomputed by another GEMM order than the forward kernel's, so the
+ * saved similarity is not guaranteed to bound it: at T <= 1e-7 a 1e-7 excess would overflow the exponential); `sim` is
+ * not read and is kept for the signature.  rowstat_scratch: [2][ld_t] floats (row maxima, row sums). */
 int dvc_corr_softmax_bwd(const float* f_blk, const float* blab, const float* gy, const float* y, const float* sim,
                          const float* gsim, const int32_t* argmax, float temperature, int32_t rows, int32_t P,
-                         int64_t chan_stride, int32_t ld_t, float* lsum_scratch, float* dS, float* dST,
+                         int64_t chan_stride, int32_t ld_t, float* rowstat_scratch, float* dS, float* dST,
                          dvcStream stream);
 
+#ifdef DVC_DEBUG
 /* ------------------------------------------------------------------------------------------------
- * Diagnostics for the timing probes under tools/ (not needed by any caller of the path; process-global switches, not
- * thread-safe; all default to off and every probe switches them off again).
+ * Diagnostics for the timing probes under tools/ — ONLY in a -DDVC_DEBUG build (`make -C csrc DEBUG=1` ->
+ * dvc_amd/libdvc_hip_debug.so); the production library has neither these symbols nor the state behind them
+ * (process-global switches, not thread-safe; all default to off and every probe switches them off again).
  *   dvc_debug_conv_trace     buf != NULL: LDS-DMA conv kernels record {entry, end of chunk loop, HW_ID, XCC_ID} per workgroup
  *   dvc_debug_conv_variant   1 / 2 / 3: skip all / patch / weight staging after the first chunk (timing only, wrong results)
  *   dvc_debug_corr_timeline  buf != NULL: per-tile s_memtime stamps of wave 0 of every correlation workgroup
@@ -344,6 +354,9 @@ void dvc_debug_conv_trace(long long* buf);
 void dvc_debug_conv_variant(int v);
 void dvc_debug_corr_timeline(long long* buf, int max_tiles);
 void dvc_debug_corr_variant(int v);
+#endif /* DVC_DEBUG */
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

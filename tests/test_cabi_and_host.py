@@ -10,9 +10,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
+def _header_symbols(debug=False):
+    """Entry points include/dvc_hip.h declares: outside (production) or inside (debug=True) its `#ifdef DVC_DEBUG` block."""
     txt = open(os.path.join(ROOT, "include", "dvc_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    dbg = re.findall(r"#ifdef DVC_DEBUG(.*?)#endif", txt, flags=re.S)
+    txt = "".join(dbg) if debug else re.sub(r"#ifdef DVC_DEBUG.*?#endif", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(dvc_[a-z0-9_]+)\s*\(", txt)))
 
 
@@ -30,8 +33,14 @@ def test_library_exports_every_declared_symbol():
     # ... and nothing with C linkage is exported that the header does not declare
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
-    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("dvc_")}
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3}
+    # -fvisibility=hidden + csrc/exports.map: no C++ internals, no host-side kernel handles, no debug hooks
     assert exported == set(syms), (sorted(exported - set(syms)), sorted(set(syms) - exported))
+    assert set(_lib.DEBUG_SIGNATURES) == set(_header_symbols(debug=True)) and not (set(_lib.DEBUG_SIGNATURES) & exported)
+    dbg_lib = os.path.join(os.path.dirname(_lib.LIB_PATH), "libdvc_hip_debug.so")
+    if os.path.exists(dbg_lib):     # the -DDVC_DEBUG build (tools/ only) adds exactly the four hooks
+        out = subprocess.run(["nm", "-D", "--defined-only", dbg_lib], capture_output=True, text=True).stdout
+        assert {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3} == set(syms) | set(_lib.DEBUG_SIGNATURES)
 
 
 def test_argument_validation_without_gpu():
@@ -168,17 +177,25 @@ def test_winograd_plan_is_a_pure_function_of_the_layer_not_of_the_batch():
         got = []
         for N in (1, 2, 5):
             d = _lib.DvcConvDesc(N, ci, H, W, co, 3, 1, dil, dil, 0, up, 1, 1, 0.0, 0, -1, 0, 0, 0, 0, 0)
-            sp = ctypes.c_int32(0)
-            assert lib.dvc_conv2d_winograd_split(ctypes.byref(d), ws, ctypes.byref(sp)) == 0, lib.dvc_last_error()
+            sp, ipl = ctypes.c_int32(0), ctypes.c_int32(0)
+            assert lib.dvc_conv2d_winograd_split(ctypes.byref(d), ws, ctypes.byref(sp), ctypes.byref(ipl)) == 0, lib.dvc_last_error()
             got.append(sp.value)
+            # images one launch covers: the whole batch unless the workspace (partial sums of the split) or the
+            # 65535-workgroup cap says otherwise — then the host must not defer the reduce (ops.conv2d_winograd)
+            cap = ws // (sp.value * co * (H * up) * (W * up) * 4) if sp.value > 1 else N
+            assert 1 <= ipl.value <= N and ipl.value <= max(cap, 1)
             assert ops.winograd_selected(N, ci, H, W, co, dil=dil, pad=dil, in_up=up) == \
                 ops.winograd_selected(1, ci, H, W, co, dil=dil, pad=dil, in_up=up)
         assert got[0] == got[1] == got[2] and 1 <= got[0] <= 8, (ci, co, H, W, got)
     # without a workspace there is nothing to split into
     d = _lib.DvcConvDesc(1, 256, 54, 96, 256, 3, 1, 1, 1, 0, 1, 1, 1, 0.0, 0, -1, 0, 0, 0, 0, 0)
-    sp = ctypes.c_int32(0)
-    assert lib.dvc_conv2d_winograd_split(ctypes.byref(d), 0, ctypes.byref(sp)) == 0 and sp.value == 1
+    sp, ipl = ctypes.c_int32(0), ctypes.c_int32(0)
+    assert lib.dvc_conv2d_winograd_split(ctypes.byref(d), 0, ctypes.byref(sp), ctypes.byref(ipl)) == 0 and sp.value == 1
+    # a batch whose partial sums do not fit the workspace is covered in several launches: images_per_launch < N
+    big = _lib.DvcConvDesc(64, 64, 216, 384, 64, 3, 1, 1, 1, 0, 1, 1, 1, 0.0, 0, -1, 2, 0, 0, 0, 0)
+    assert lib.dvc_conv2d_winograd_split(ctypes.byref(big), ws, ctypes.byref(sp), ctypes.byref(ipl)) == 0
+    assert sp.value == 2 and ipl.value == ws // (2 * 64 * 216 * 384 * 4) < 64
     # a layer the kernel does not take is refused with a message, not planned
     bad = _lib.DvcConvDesc(1, 3, 54, 96, 64, 3, 1, 1, 1, 0, 1, 1, 1, 0.0, 0, -1, 0, 0, 0, 0, 0)
-    assert lib.dvc_conv2d_winograd_split(ctypes.byref(bad), ws, ctypes.byref(sp)) != 0
+    assert lib.dvc_conv2d_winograd_split(ctypes.byref(bad), ws, ctypes.byref(sp), ctypes.byref(ipl)) != 0
     assert b"Cin" in lib.dvc_last_error()

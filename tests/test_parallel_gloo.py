@@ -76,6 +76,9 @@ def _worker(rank, world, port, cache, q):
     frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W) for i in range(NF)]
     IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
     cc = OracleColorizer(sd, cache)
+    n_bcast = []
+    real_broadcast = dist.broadcast
+    dist.broadcast = lambda t, src, *a, **k: (n_bcast.append(t.numel() * t.element_size()), real_broadcast(t, src, *a, **k))[1]
     lo, hi, outs, full = parallel.colorize_clip_sharded(cc, frames, IB if rank == 0 else None,
                                                         torch.device("cpu"), gather=True)
     # single-process reference for this rank's chunk
@@ -83,7 +86,9 @@ def _worker(rank, world, port, cache, q):
     ref.set_exemplar(IB)
     want = ref.clip(frames[lo:hi])
     ok_local = all(torch.equal(a, b) for a, b in zip(outs, want)) and len(outs) == hi - lo
+    dist.broadcast = real_broadcast
     ok_ex = torch.equal(cc.IB_lab, IB) and (not cache or rank == 0 or cc.n_set_exemplar == 0)
+    ok_ex = ok_ex and len(n_bcast) == 1       # ONE collective per clip: exemplar Lab + cache tensors in one flat buffer
     ok_full = len(full) == NF and all(torch.equal(full[lo + i], outs[i]) for i in range(hi - lo))
     q.put((rank, lo, hi, ok_local, ok_ex, ok_full))
     dist.barrier()
@@ -105,6 +110,16 @@ def test_sharded_clip_world2_gloo(cache):
     assert [(r[1], r[2]) for r in res] == [(0, 3), (3, 5)]
     for r in res:
         assert r[3] and r[4] and r[5], r
+
+
+def test_flat_layout_is_aligned_and_dense():
+    from dvc_amd.parallel import flat_layout
+    spec = [((1, 3, 216, 384), torch.float32), ((1, 5184, 256), torch.int16), ((1, 3, 5), torch.float32), ((7,), torch.uint8)]
+    offs, total = flat_layout(spec)
+    assert offs[0] == 0 and all(o % 16 == 0 for o in offs) and total % 16 == 0
+    sizes = [3 * 216 * 384 * 4, 5184 * 256 * 2, 60, 7]
+    for o, n, nxt in zip(offs, sizes, offs[1:] + [total]):
+        assert o + n <= nxt < o + n + 16
 
 
 def test_chunk_bounds_cover_and_balance():

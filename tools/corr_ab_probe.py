@@ -5,6 +5,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deep-exemplar-based-video-colorization_amd"))
+os.environ.setdefault("DVC_DEBUG_LIB", "1")   # the dvc_debug_* hooks live in the -DDVC_DEBUG build (make -C csrc DEBUG=1)
 import torch  # noqa: E402
 
 from dvc_amd import _lib, ops  # noqa: E402
