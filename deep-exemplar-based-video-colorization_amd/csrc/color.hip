@@ -67,31 +67,36 @@ extern "C" int dvc_lab2rgb(const float* lab, int32_t N, int32_t HW, float l_offs
 }
 
 // models/FrameColor.py:63-64: channels [L | warped a,b | similarity | last L,a,b]
-__global__ __launch_bounds__(256) void pack_color_input_kernel(const float* __restrict__ IA_lab,
+// The previous frame arrives as its two parts — the luminance plane (channel 0 of the previous INPUT frame) and the
+// previous ab prediction — so that the caller never has to materialise cat(IA_l, ab) (test.py:96) between frames.
+__global__ __launch_bounds__(256) void pack_color_input_kernel(const float* __restrict__ IA_l, long ia_bs,
                                                                const float* __restrict__ warped,
                                                                const float* __restrict__ sim,
-                                                               const float* __restrict__ last, long HW,
+                                                               const float* __restrict__ last_l, long ll_bs,
+                                                               const float* __restrict__ last_ab, long lab_bs, long HW,
                                                                float* __restrict__ out) {
     const int n = blockIdx.y;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
         float* o = out + (long)n * 7 * HW + i;
-        o[0] = IA_lab[(long)n * 3 * HW + i];
+        o[0] = IA_l[(long)n * ia_bs + i];
         o[HW] = warped[(long)n * 3 * HW + HW + i];
         o[2 * HW] = warped[(long)n * 3 * HW + 2 * HW + i];
         o[3 * HW] = sim[(long)n * HW + i];
-        o[4 * HW] = last[(long)n * 3 * HW + i];
-        o[5 * HW] = last[(long)n * 3 * HW + HW + i];
-        o[6 * HW] = last[(long)n * 3 * HW + 2 * HW + i];
+        o[4 * HW] = last_l[(long)n * ll_bs + i];
+        o[5 * HW] = last_ab[(long)n * lab_bs + i];
+        o[6 * HW] = last_ab[(long)n * lab_bs + HW + i];
     }
 }
 
-extern "C" int dvc_pack_color_input(const float* IA_lab, const float* warped_lab, const float* sim,
-                                    const float* IA_last_lab, int32_t N, int32_t HW, float* out7,
-                                    dvcStream stream) {
-    DVC_REQUIRE(IA_lab && warped_lab && sim && IA_last_lab && out7 && N > 0 && HW > 0,
+extern "C" int dvc_pack_color_input(const float* IA_l, int64_t ia_batch_stride, const float* warped_lab, const float* sim,
+                                    const float* last_l, int64_t last_l_batch_stride, const float* last_ab,
+                                    int64_t last_ab_batch_stride, int32_t N, int32_t HW, float* out7, dvcStream stream) {
+    DVC_REQUIRE(IA_l && warped_lab && sim && last_l && last_ab && out7 && N > 0 && HW > 0,
                 "dvc_pack_color_input: bad argument");
     hipLaunchKernelGGL(pack_color_input_kernel, dim3(cdiv(HW, 1024), N), dim3(256), 0,
-                       (hipStream_t)stream, IA_lab, warped_lab, sim, IA_last_lab, (long)HW, out7);
+                       (hipStream_t)stream, IA_l, ia_batch_stride ? (long)ia_batch_stride : (long)HW, warped_lab, sim, last_l,
+                       last_l_batch_stride ? (long)last_l_batch_stride : (long)HW, last_ab,
+                       last_ab_batch_stride ? (long)last_ab_batch_stride : 2L * HW, (long)HW, out7);
     DVC_CHECK_LAUNCH("dvc_pack_color_input");
     return 0;
 }

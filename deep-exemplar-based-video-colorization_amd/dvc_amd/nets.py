@@ -20,6 +20,15 @@ from . import arch, ops
 _VGG_MEAN_BGR = (0.40760392, 0.45795686, 0.48501961)  # utils/util.py:351
 
 
+_pack_epoch = 0
+
+
+def pack_epoch():
+    """Number of weight (re)packs so far in this process: a captured launch sequence (dvc_amd/graph.py) bakes the packed
+    tensors' addresses in and is re-captured when this has moved (load_state_dict, .cuda(), another conv algorithm)."""
+    return _pack_epoch
+
+
 class _PackCache:
     """Repacked weights ([Cin][k*k][Cout]) keyed by parameter identity + version, so an in-place
     `load_state_dict` or a `.cuda()` move is picked up on the next forward."""
@@ -38,6 +47,8 @@ class _PackCache:
             # entry is complete before any stream can see it.  `prepare()` takes all misses up front.
             if param.is_cuda:
                 torch.cuda.synchronize(param.device)
+            global _pack_epoch
+            _pack_epoch += 1
             with torch.no_grad():
                 hit = (tag, fn(param))
             if param.is_cuda:
@@ -102,13 +113,13 @@ class VGG19_pytorch(nn.Module):
             return self._cache.get(name + ":bgr", conv.weight, lambda w: ops.pack_conv_weight(w.flip(1)))
         return self._cache.get(name, conv.weight, ops.pack_conv_weight)
 
-    def _pre_affine(self):
-        """vgg_preprocess (utils/util.py:347-352) as a per-channel affine on the stored R,G,B channels:
-        BGR channel c' = 2-c gets (x - mean[c'])*255 = x*255 - 255*mean[c']."""
+    def _pre_affine(self, N=1):
+        """vgg_preprocess (utils/util.py:347-352) as a per-(image, channel) affine on the stored R,G,B channels:
+        BGR channel c' = 2-c gets (x - mean[c'])*255 = x*255 - 255*mean[c'].  [N*3] each, built once per batch size."""
         w = self.conv1_1.weight
-        sc = self._cache.get("pre:scale", w, lambda w: torch.full((3,), 255.0, device=w.device))
-        sh = self._cache.get("pre:shift", w, lambda w: torch.tensor(
-            [-255.0 * _VGG_MEAN_BGR[2], -255.0 * _VGG_MEAN_BGR[1], -255.0 * _VGG_MEAN_BGR[0]], device=w.device))
+        sc = self._cache.get(f"pre:scale:{N}", w, lambda w: torch.full((3 * N,), 255.0, device=w.device))
+        sh = self._cache.get(f"pre:shift:{N}", w, lambda w: torch.tensor(
+            [-255.0 * _VGG_MEAN_BGR[2], -255.0 * _VGG_MEAN_BGR[1], -255.0 * _VGG_MEAN_BGR[0]] * N, device=w.device))
         return sc, sh
 
     def prepare(self):
@@ -140,9 +151,9 @@ class VGG19_pytorch(nn.Module):
                 bias = conv.bias.detach()
                 if name == "conv1_1" and preprocess:
                     # vgg_preprocess folded into the load (BGR weight flip + per-channel affine)
-                    sc, sh = self._pre_affine()
+                    sc, sh = self._pre_affine(N)
                     cur = ops.conv2d(cur, self._packed(name, swap_bgr=True), bias, act=ops.ACT_RELU,
-                                     in_scale=sc.repeat(N), in_shift=sh.repeat(N))
+                                     in_scale=sc, in_shift=sh)
                 else:
                     cur = ops.conv3x3(cur, conv.weight, _packs(self._cache, name, conv.weight), bias, act=ops.ACT_RELU)
             out[key] = cur

@@ -524,13 +524,38 @@ def lab2rgb(lab, l_offset=0.0):
     return y
 
 
-def pack_color_input(IA_lab, warped_lab, sim, IA_last_lab):
+def _plane(t, ch, name):
+    """(pointer, batch stride in elements) of channels ch.. of an [N,C,H,W] fp32 device tensor whose planes are dense
+    (a contiguous tensor, or a channel slice of one)."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4):
+        raise RuntimeError(f"dvc_amd: `{name}` must be a 4-d float32 ROCm device tensor; no CPU fallback")
+    if t.device.index != _current_device():
+        raise RuntimeError(f"dvc_amd: `{name}` lives on {t.device} but the current device is cuda:{_current_device()}")
+    N, C, H, W = t.shape
+    if t.stride(3) != 1 or t.stride(2) != W or (C > 1 and t.stride(1) != H * W):
+        raise RuntimeError(f"dvc_amd: `{name}` must have dense planes (a contiguous tensor or a channel slice of one)")
+    return ctypes.c_void_p(t.data_ptr() + 4 * ch * H * W), (t.stride(0) if N > 1 else C * H * W)
+
+
+def pack_color_input(IA_lab, warped_lab, sim, IA_last_lab=None, *, last_l=None, last_ab=None, out=None):
+    """cat((IA_l, warped ab, similarity, IA_last_lab), 1)  (FrameColor.py:63-64).  IA_lab: the current frame (channel 0 is
+    read; a Lab tensor or its [:, 0:1] slice).  The previous frame is either `IA_last_lab` [N,3,H,W] or its two parts
+    `last_l` (a tensor whose channel 0 is the previous luminance, e.g. the previous Lab frame) and `last_ab` [N,2,H,W] — the
+    clip loop passes the parts and never builds test.py:96's cat.  `out`: an existing [N,7,H,W] tensor (graph replay)."""
     lib = _lib.load()
-    for t, nm in ((IA_lab, "IA_lab"), (warped_lab, "warped_lab"), (sim, "sim"), (IA_last_lab, "IA_last_lab")):
+    for t, nm in ((warped_lab, "warped_lab"), (sim, "sim")):
         _need(t, nm)
     N, _, H, W = IA_lab.shape
-    y = torch.empty((N, 7, H, W), device=IA_lab.device, dtype=torch.float32)
-    _lib.check(lib.dvc_pack_color_input(_p(IA_lab), _p(warped_lab), _p(sim), _p(IA_last_lab), N, H * W, _p(y),
+    ia, ia_bs = _plane(IA_lab, 0, "IA_lab")
+    if IA_last_lab is not None:
+        ll, ll_bs = _plane(IA_last_lab, 0, "IA_last_lab")
+        la, la_bs = _plane(IA_last_lab, 1, "IA_last_lab")
+    else:
+        ll, ll_bs = _plane(last_l, 0, "last_l")
+        la, la_bs = _plane(last_ab, 0, "last_ab")
+        assert last_ab.shape[1] == 2
+    y = torch.empty((N, 7, H, W), device=IA_lab.device, dtype=torch.float32) if out is None else out
+    _lib.check(lib.dvc_pack_color_input(ia, ia_bs, _p(warped_lab), _p(sim), ll, ll_bs, la, la_bs, N, H * W, _p(y),
                                         _stream()), "dvc_pack_color_input")
     return y
 
@@ -549,14 +574,36 @@ def corr_prepare(t_raw, eps=EPS64):
 
 
 _ws_cache = {}
+_ws_scope = None
+
+
+class workspace_scope:
+    """While active, scratch buffers come from `store` (a dict the caller owns) instead of the per-stream cache: a captured
+    launch sequence (dvc_amd/graph.py) bakes its workspace addresses in and may be replayed on any stream, next to eager
+    launches or other graphs that use that stream's workspaces — so every capture gets private ones."""
+
+    def __init__(self, store):
+        self.store = store
+
+    def __enter__(self):
+        global _ws_scope
+        self.prev, _ws_scope = _ws_scope, self.store
+        return self.store
+
+    def __exit__(self, *exc):
+        global _ws_scope
+        _ws_scope = self.prev
 
 
 def _workspace(device, nbytes, tag="corr"):
-    key = (tag, device.index, _stream_handle())
-    ws = _ws_cache.get(key)
+    if _ws_scope is not None:
+        cache, key = _ws_scope, (tag, device.index)
+    else:
+        cache, key = _ws_cache, (tag, device.index, _stream_handle())
+    ws = cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
-        _ws_cache[key] = ws
+        cache[key] = ws
     return ws
 
 

@@ -207,10 +207,15 @@ int dvc_gray2rgb(const float* l, int32_t N, int32_t HW, int64_t l_batch_stride, 
  * l_offset == 0; pass l_offset = 50 to fold uncenter_l, utils/util.py:63-64) -> sRGB [0,1]. */
 int dvc_lab2rgb(const float* lab, int32_t N, int32_t HW, float l_offset, float* rgb,
                 dvcStream stream);
-/* cat((IA_l, nonlocal_BA_lab[:,1:3], similarity_map, IA_last_lab), 1): models/FrameColor.py:63-64. */
-int dvc_pack_color_input(const float* IA_lab, const float* warped_lab, const float* sim,
-                         const float* IA_last_lab, int32_t N, int32_t HW, float* out7,
-                         dvcStream stream);
+/* cat((IA_l, nonlocal_BA_lab[:,1:3], similarity_map, IA_last_lab), 1): models/FrameColor.py:63-64 -> out7 [N][7][HW].
+ * IA_l: the luminance plane of the current frame (element stride between images `ia_batch_stride`, 0 = HW; 3 HW when it
+ * is channel 0 of a Lab tensor).  IA_last_lab arrives as its two parts, so that the clip loop never materialises
+ * test.py:96's cat((IA_l, ab_predict)) between frames: last_l = luminance plane of the previous frame, last_ab = the
+ * previous [N][2][HW] prediction (batch strides 0 = HW / 2 HW); for an existing Lab tensor pass (lab, 3 HW, lab + HW, 3 HW).
+ * warped_lab: [N][3][HW] (channels 1, 2 are read); sim: [N][1][HW]. */
+int dvc_pack_color_input(const float* IA_l, int64_t ia_batch_stride, const float* warped_lab, const float* sim,
+                         const float* last_l, int64_t last_l_batch_stride, const float* last_ab,
+                         int64_t last_ab_batch_stride, int32_t N, int32_t HW, float* out7, dvcStream stream);
 
 /* ---- clip-driver tail, test.py:98-116 ------------------------------------------------
  * F.interpolate(x, scale_factor=2, mode="bilinear") * mul on `planes` planes of H x W (test.py:100-102; ATen's

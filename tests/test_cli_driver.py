@@ -128,3 +128,65 @@ def test_colorize_video_end_to_end(tmp_path, frame_propagate, monkeypatch):
     if not frame_propagate:                            # the exemplar matters: another reference, other colours
         other = cc.colorize_video(dev, torch.from_numpy(_smooth_rgb(8, 200, 300)).cuda(), image_size=size)
         assert not np.array_equal(other[0].cpu().numpy(), outs[32][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frame_propagate", [False, True])
+def test_cli_colorize_video_against_the_composed_oracle(tmp_path, frame_propagate, monkeypatch):
+    """The WHOLE chain of test.py:29-124 against the oracle's composition of it (oracle/video_oracle.py: ingest_oracle ->
+    dvc_oracle.frame_colorization recurrence -> tail_oracle.frame_tail), not against the product's own ClipColorizer:
+    a folder of PNG frames + a reference image go through cli.colorize_video (PIL decode, device ingest, networks, WLS
+    filter, 8-bit RGB, batches of 2 that continue the recurrence) and the arrays handed to save_frames are compared with
+    the oracle's frames.  Tolerance: at most one 8-bit level on at most 0.1 % of the values of every frame — the
+    stage-level statements of tests/test_ingest.py / test_tail.py (float64 results that sit on an integer truncate either
+    way) composed; the ab predictions in between within the north-star 1e-3 wherever no query row is a near-tie."""
+    import contextlib
+    import io
+    from PIL import Image
+    from dvc_amd import cli, synth
+    from models.ColorVidNet import ColorVidNet
+    from models.NonlocalNet import VGG19_pytorch, WarpNet
+    from oracle import video_oracle
+    clip = tmp_path / "clips" / "c2"
+    os.makedirs(clip)
+    H0, W0 = 180, 320
+    order = [3, 10, 1, 22]
+    imgs = {}
+    for k, num in enumerate(order):
+        imgs[num] = _smooth_rgb(200 + k, H0, W0)
+        Image.fromarray(imgs[num]).save(str(clip / f"{num}.png"))
+    ref = _smooth_rgb(9, 200, 300)
+    Image.fromarray(ref).save(str(tmp_path / "ref.png"))
+    sd = (synth.vgg19_state_dict(0), synth.warpnet_state_dict(0), synth.colorvidnet_state_dict(0, contractive=True))
+    with contextlib.redirect_stdout(io.StringIO()):
+        nets = (VGG19_pytorch(), WarpNet(1), ColorVidNet(7))
+    for m, s_ in zip(nets, sd):
+        m.load_state_dict(s_)
+        m.eval().cuda()
+    vgg, warp, col = nets
+    saved = []
+    real_save = cli.save_frames
+    monkeypatch.setattr(cli, "save_frames", lambda image, folder, index=None, image_name=None:
+                        (saved.append(np.array(image)), real_save(image, folder, index, image_name))[1])
+    size = [96, 160]
+    opt = cli.build_parser().parse_args(["--frame_propagate", "1"] if frame_propagate else [])
+    opt.image_size, opt.batch_frames = size, 2
+    cli.colorize_video(opt, str(clip) + "/", str(tmp_path / "ref.png"), str(tmp_path / "out"), warp, col, vgg)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    taps = {}
+    want = video_oracle.colorize_video([imgs[n] for n in sorted(order)], ref, size, *sd, frame_propagate=frame_propagate,
+                                       taps=taps)
+    assert len(saved) == len(want) == len(order)
+    lines = []
+    for i, (a, w) in enumerate(zip(saved, want)):
+        assert a.shape == w.shape == (size[0], size[1], 3) and a.dtype == np.uint8
+        d = np.abs(a.astype(np.int16) - w.astype(np.int16))
+        frac = float((d > 0).mean())
+        lines.append(f"frame{i}: max level diff {int(d.max())}, differing values {frac * 100:.4f} % (oracle min affinity gap {taps['min_gap'][i]:.1e})")
+        if taps["min_gap"][i] > 2e-6:          # (a near-tie row may legitimately pick the other exemplar position)
+            assert d.max() <= 1 and frac <= 1e-3, (i, int(d.max()), frac)
+    rep = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "test_report.txt")
+    os.makedirs(os.path.dirname(rep), exist_ok=True)
+    with open(rep, "a") as f:
+        f.write(f"cli.colorize_video vs composed oracle (frame_propagate={frame_propagate}): " + "; ".join(lines) + "\n")
+    assert any(g > 2e-6 for g in taps["min_gap"])

@@ -124,3 +124,32 @@ def test_contractive_weight_set_is_reproducible_across_thread_counts():
         truth = O.colorize_clip([f.double() for f in frames], IB.double(), *sd64, temperature=T)
     for i, (a, t) in enumerate(zip(runs[0], truth)):
         assert (a.double() - t).abs().max().item() < 2e-4, i
+
+
+def test_video_oracle_is_the_composition_of_its_parts():
+    """oracle/video_oracle.py (test.py:29-124 minus file I/O) = ingest_oracle.frame_ingest -> x0.5 -> dvc_oracle.colorize_clip
+    -> tail_oracle.frame_tail, frame by frame, in both recurrence modes."""
+    import numpy as np
+    from dvc_amd import synth
+    from oracle import dvc_oracle as O, ingest_oracle, tail_oracle, video_oracle
+    torch.set_num_threads(1)
+    sd = (synth.vgg19_state_dict(0), synth.warpnet_state_dict(0), synth.colorvidnet_state_dict(0, contractive=True))
+    rng = np.random.default_rng(5)
+    def img(h, w):
+        base = torch.from_numpy(rng.random((1, 3, 4, 6), dtype=np.float32))
+        x = torch.nn.functional.interpolate(base, (h, w), mode="bilinear", align_corners=False)
+        return np.ascontiguousarray((x[0].permute(1, 2, 0) * 255).round().to(torch.uint8).numpy())
+    frames, ref, size = [img(70, 120), img(70, 120)], img(64, 100), [64, 96]
+    for fp in (False, True):
+        taps = {}
+        got = video_oracle.colorize_video(frames, ref, size, *sd, frame_propagate=fp, taps=taps)
+        large = [torch.from_numpy(ingest_oracle.frame_ingest(f, size))[None] for f in frames]
+        ref_large = large[0] if fp else torch.from_numpy(ingest_oracle.frame_ingest(ref, size))[None]
+        small = [torch.from_numpy(tail_oracle.downsample_half(t.numpy())) for t in large]
+        IB = torch.from_numpy(tail_oracle.downsample_half(ref_large.numpy()))
+        with torch.no_grad():
+            abs_ = O.colorize_clip(small, IB, *sd, temperature=1e-10, frame_propagate=fp)
+        for g, L, ab, ab_t in zip(got, large, abs_, taps["ab"]):
+            assert torch.equal(ab, ab_t)
+            want, _ = tail_oracle.frame_tail(L[:, 0:1].numpy(), ab.numpy())
+            assert g.dtype == np.uint8 and g.shape == (64, 96, 3) and np.array_equal(g, want)
