@@ -218,6 +218,9 @@ def main():
                     help="frames per front-end batch of the clip driver (bit-identical to 1: the library plans per image)")
     ap.add_argument("--lookahead", type=int, default=2,
                     help="frames whose front end runs ahead on side HIP streams (0 = per-frame calls on one stream)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="issue every kernel launch from Python instead of replaying the captured per-frame launch sequences "
+                         "(hipGraph, dvc_amd/graph.py); results are bit-identical either way")
     ap.add_argument("--no-autotune", action="store_true", help="use the static tile cost model instead of first-use timing")
     ap.add_argument("--corr", choices=["fp32", "bf16"], default="fp32",
                     help="bf16 = BASELINE configs[4]: bf16 MFMA candidate filter + exact fp32 re-scoring")
@@ -283,7 +286,8 @@ def main():
     ops.set_autotune(not args.no_autotune)   # like the reference's cudnn.benchmark = True (test.py:140)
     nets, sd = build_nets(device)
     nets[1].corr_precision = args.corr
-    cc = ClipColorizer(*nets, temperature=1e-10, cache_exemplar=not args.no_exemplar_cache)
+    use_graph = not args.no_graph and not args.no_exemplar_cache and args.front_batch == 1
+    cc = ClipColorizer(*nets, temperature=1e-10, cache_exemplar=not args.no_exemplar_cache, graph=use_graph)
     # exemplar: prepared on rank 0, shared once with every rank (RCCL broadcast over xGMI)
     IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).to(device)
     broadcast_exemplar(cc, IB if rank == 0 else None, (1, 3, H, W), device, src=0)
@@ -346,6 +350,17 @@ def main():
         torch.cuda.synchronize()
         seq_fps = K / (time.perf_counter() - t1)
         assert torch.equal(last_seq, last_timed), "pipelined clip driver != per-frame loop"
+    # ... and, when the timed region replayed captured launch sequences, the same K frames with every launch issued from
+    # Python (what r01/r02 timed): reported next to `value`, and required to give the same predictions bit for bit
+    eager_fps = None
+    if use_graph and args.lookahead > 0 and rank == 0:
+        cc.clip(frames[:Wm], lookahead=args.lookahead, graph=False)          # (side-stream allocator pools)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        cc.clip(frames[Wm:Wm + K], last=last, lookahead=args.lookahead, graph=False)
+        torch.cuda.synchronize()
+        eager_fps = K / (time.perf_counter() - t1)
+        assert torch.equal(cc.last_lab, last_timed), "hipGraph replay != eager launches"
     last = last_timed
     if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -430,7 +445,11 @@ def main():
                        f"ClipColorizer.clip: front end of the next {args.lookahead} frames on side HIP streams, " +
                        (f"{args.front_batch} frames per set of front-end launches (planned per image), " if args.front_batch > 1 else "") +
                        "ColorVidNet recurrence on the main stream (bit-identical to per-frame calls)",
-                       "per_frame_api_frames_per_s": None if seq_fps is None else round(seq_fps, 3)},
+                       "launches": "captured per-frame launch sequences replayed as hipGraphs (front end per side stream, "
+                                   "ColorVidNet chain), bit-identical to eager launches" if use_graph else
+                                   "every kernel launched from Python",
+                       "per_frame_api_frames_per_s": None if seq_fps is None else round(seq_fps, 3),
+                       "eager_launch_clip_driver_frames_per_s": None if eager_fps is None else round(eager_fps, 3)},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

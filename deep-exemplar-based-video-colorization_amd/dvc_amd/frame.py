@@ -53,16 +53,59 @@ def frame_colorization(IA_lab, IB_lab, IA_last_lab, features_B, vggnet, nonlocal
     return IA_ab_predict, nonlocal_BA_lab, features_A_gray
 
 
+class _FrontSlot:
+    """One captured front end (dvc_amd/graph.py): static input frame -> (warped Lab, similarity map) at fixed addresses."""
+
+    def __init__(self, cc, shape, device, stream):
+        from .graph import CapturedSequence
+        self.IA_in = torch.zeros(shape, device=device, dtype=torch.float32)
+        self.consumed = None        # event: the last reader of .warped / .sim has been enqueued up to here
+
+        def front():
+            warped, sim, _ = warp_color(self.IA_in[:, 0:1], cc.IB_lab, None, cc.vgg, cc.warp, cc.col, 0,
+                                        temperature=cc.temperature, exemplar_cache=cc.ex_cache)
+            return warped, sim
+
+        self.seq = CapturedSequence(front, stream)
+        self.warped, self.sim = self.seq.out
+
+
+class _ColorChain:
+    """The captured ColorVidNet chain: static 7-channel input -> ab prediction at a fixed address."""
+
+    def __init__(self, cc, shape, device, stream):
+        from .graph import CapturedSequence
+        n, _, H, W = shape
+        self.cin = torch.zeros((n, 7, H, W), device=device, dtype=torch.float32)
+        self.seq = CapturedSequence(lambda: cc.col(self.cin), stream)
+        self.ab = self.seq.out
+
+
 class ClipColorizer:
     """Per-clip driver around `frame_colorization` (the hot loop of /root/reference/test.py:57-96):
     the exemplar's VGG features and its whole WarpNet side (heads, trunk, phi, pooled Lab) are computed
     once per clip instead of once per frame — identical results, 52.6 GFLOP/frame less work
-    (SURVEY.md §3.1 "Redundancy")."""
+    (SURVEY.md §3.1 "Redundancy").
 
-    def __init__(self, vggnet, nonlocal_net, colornet, temperature=1e-10, cache_exemplar=True):
+    graph=True: the per-frame launch sequences (front end, ColorVidNet chain) are captured once per frame geometry into
+    hipGraphs and replayed (dvc_amd/graph.py) — bit-identical results.  The per-frame call `frame()` replays both (2 graph
+    launches + 4 small kernels instead of ~120 launches: 0.09 instead of 1.56 ms of host time per frame); the pipelined
+    `clip()` replays the look-ahead front ends and keeps launching the ColorVidNet chain on the high-priority stream (see
+    `graph_parts`).  Needs the exemplar cache (the captured front end reads the cached exemplar side at fixed addresses;
+    `set_exemplar` refreshes those buffers in place for the next clip)."""
+
+    def __init__(self, vggnet, nonlocal_net, colornet, temperature=1e-10, cache_exemplar=True, graph=False):
         self.vgg, self.warp, self.col = vggnet, nonlocal_net, colornet
         self.temperature = temperature
         self.cache_exemplar = cache_exemplar
+        self.graph = bool(graph)
+        # which sequences the PIPELINED driver replays: "front" (default) = the look-ahead front ends, with the ColorVidNet
+        # chain launched kernel by kernel on the high-priority stream.  Measured on the MI355X (profiles/
+        # r03_graph_overlap_probe.txt): a replayed graph puts its whole backlog of packets into its hardware queue at once,
+        # and a high-priority queue with a backlog starves the low-priority ones — both sequences replayed: 3.44 ms/frame
+        # (the front ends only run while the recurrence stream is empty), without stream priorities 2.58; front ends
+        # replayed + chain launched eagerly 2.40; everything eager 2.48.  "all" / "color" remain for that probe.
+        self.graph_parts = "front"
         self.IB_lab = None
         self.features_B = None
         self.ex_cache = None
@@ -70,6 +113,8 @@ class ClipColorizer:
         self._side_streams = []
         self._main_stream = None
         self._tail_stream = None
+        self._graph_stream = None
+        self._graphs = {}            # (kind, shape, slot) -> _FrontSlot / _ColorChain
 
     def prepare(self):
         """Pack all weights of the three networks on the current stream (idempotent, cheap when warm)."""
@@ -84,11 +129,29 @@ class ClipColorizer:
         self.IB_lab = IB_lab
         rgb = ops.lab2rgb(IB_lab, l_offset=50.0)   # uncenter_l folded into the kernel
         self.features_B = self.vgg(rgb, VGG_OUT, preprocess=True)
+        old = self.ex_cache
         self.ex_cache = None
         if self.cache_exemplar:
             nB = [feature_normalize(t) for t in self.features_B[1:]]
-            self.ex_cache = self.warp.exemplar_side(IB_lab, *nB, bf16=self.warp._use_bf16(self.temperature, 1))
+            new = self.warp.exemplar_side(IB_lab, *nB, bf16=self.warp._use_bf16(self.temperature, 1))
+            self.ex_cache = self._install_cache(old, new)
         return self.features_B
+
+    def _install_cache(self, old, new):
+        """Captured front ends read the exemplar cache at the addresses it had at capture time: a new exemplar of the same
+        geometry is copied INTO the existing buffers (all streams drained first: a replay in flight may still read them)."""
+        if not self._graphs or old is None:
+            self._graphs.clear()
+            return new
+        flat = lambda c: (list(c[0]) if isinstance(c[0], tuple) else [c[0]]) + [c[1]]   # noqa: E731
+        fo, fn = flat(old), flat(new)
+        if len(fo) != len(fn) or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(fo, fn)):
+            self._graphs.clear()
+            return new
+        torch.cuda.synchronize()
+        for a, b in zip(fo, fn):
+            a.copy_(b)
+        return old
 
     def exemplar_cache_spec(self, lab_shape):
         """[(shape, dtype)] of the flat tensor list `exemplar_cache_tensors()` yields for an exemplar of
@@ -116,15 +179,48 @@ class ClipColorizer:
         tensors = list(tensors)
         self.IB_lab = IB_lab
         self.features_B = None          # not needed once the exemplar side is cached
-        self.ex_cache = ((tensors[0], tensors[1]), tensors[2]) if len(tensors) == 3 else (tensors[0], tensors[1])
+        new = ((tensors[0], tensors[1]), tensors[2]) if len(tensors) == 3 else (tensors[0], tensors[1])
+        self.ex_cache = self._install_cache(self.ex_cache, new)
 
-    def frame(self, IA_lab, IA_last_lab):
+    # ---- captured launch sequences ------------------------------------------------------------------------------
+    def _captured(self, kind, shape, device, slot, stream):
+        key = (kind, tuple(shape), slot)
+        g = self._graphs.get(key)
+        if g is None or g.seq.stale():
+            if self.ex_cache is None:
+                raise RuntimeError("ClipColorizer(graph=True) needs the exemplar cache (cache_exemplar=True + set_exemplar)")
+            self.prepare()
+            g = (_FrontSlot if kind == "front" else _ColorChain)(self, shape, device, stream)
+            self._graphs[key] = g
+        return g
+
+    def _capture_stream(self):
+        if self._graph_stream is None:
+            self._graph_stream = torch.cuda.Stream()
+        return self._graph_stream
+
+    def frame(self, IA_lab, IA_last_lab, graph=None):
+        """One frame_colorization call (the per-frame API of test.py:85): returns (ab, warped Lab)."""
+        if self.graph if graph is None else graph:
+            return self._frame_graph(IA_lab.detach().contiguous().float(),
+                                     dict(IA_last_lab=IA_last_lab.detach().contiguous().float()))
         ab, nl, _ = frame_colorization(IA_lab, self.IB_lab, IA_last_lab, self.features_B, self.vgg, self.warp,
                                        self.col, joint_training=False, feature_noise=0,
                                        temperature=self.temperature, exemplar_cache=self.ex_cache)
         return ab, nl
 
-    def clip(self, frames_lab, frame_propagate=False, last=None, lookahead=2, on_frame=None, front_batch=1):
+    def _frame_graph(self, IA_lab, prev):
+        """The per-frame call as two graph replays on the CURRENT stream (no look-ahead is possible through this API: the
+        next frame is not known).  The outputs are cloned out of the graphs' arenas (the next call overwrites them)."""
+        front = self._captured("front", IA_lab.shape, IA_lab.device, "seq", self._capture_stream())
+        chain = self._captured("color", IA_lab.shape, IA_lab.device, 0, self._capture_stream())
+        front.IA_in.copy_(IA_lab)
+        front.seq.replay()
+        ops.pack_color_input(IA_lab, front.warped, front.sim, out=chain.cin, **prev)
+        chain.seq.replay()
+        return chain.ab.clone(), front.warped.clone()
+
+    def clip(self, frames_lab, frame_propagate=False, last=None, lookahead=2, on_frame=None, front_batch=1, graph=None):
         """Recurrence of test.py:68-96; returns the list of ab predictions.
 
         Only ColorVidNet(t) consumes frame t-1's prediction (test.py:96 -> FrameColor.py:63-64); the
@@ -139,23 +235,36 @@ class ClipColorizer:
         takes 24 % less time as one batch on an otherwise idle GPU, but inside this driver the other stream already fills
         those gaps — 384-388 frames/s for every batch size — so the default stays 1; the option matters where the host's
         launch rate is the limit.)
+        `graph` (default: the constructor's): replay captured launch sequences instead of issuing the launches — one
+        hipGraph per side stream for the front end, one for the ColorVidNet chain; same streams, events and priorities.
         `last` (optional) continues the recurrence from an earlier call.  `on_frame(t, IA_lab, ab)`
         (optional) is called right after frame t's launches have been issued, with the recurrence stream
-        current — the hook `clip_rgb` hangs the per-frame tail on."""
-        frames_lab = list(frames_lab)
+        current — the hook `clip_rgb` hangs the per-frame tail on.
+        The previous frame reaches ColorVidNet as its two parts (luminance plane of the previous input frame, previous ab
+        prediction: ops.pack_color_input), so test.py:96's cat((IA_l, ab)) is built once, at the end, for `last_lab`."""
+        frames_lab = [f.detach().contiguous().float() for f in frames_lab]
         if not frames_lab:
             return []
+        use_graph = self.graph if graph is None else bool(graph)
         if last is None:
             last = self.IB_lab if frame_propagate else torch.zeros_like(frames_lab[0])
+        last = last.detach().contiguous().float()
+        prev = dict(IA_last_lab=last)          # how the previous frame is handed to pack_color_input
         outs = []
         if lookahead <= 0 or len(frames_lab) < 2:
             for IA_lab in frames_lab:
-                ab, _ = self.frame(IA_lab, last)
-                last = torch.cat((IA_lab[:, 0:1], ab), dim=1)   # test.py:96 (pure data movement)
+                if use_graph:
+                    ab, _ = self._frame_graph(IA_lab, prev)
+                else:
+                    IA_l = IA_lab[:, 0:1]
+                    warped, sim, _ = warp_color(IA_l, self.IB_lab, self.features_B, self.vgg, self.warp, self.col, 0,
+                                                temperature=self.temperature, exemplar_cache=self.ex_cache)
+                    ab = self.col(ops.pack_color_input(IA_lab, warped, sim, **prev))
+                prev = dict(last_l=IA_lab, last_ab=ab)
                 outs.append(ab)
                 if on_frame is not None:
                     on_frame(len(outs) - 1, IA_lab, ab)
-            self.last_lab = last
+            self.last_lab = torch.cat((frames_lab[-1][:, 0:1], outs[-1]), dim=1)   # test.py:96 (pure data movement)
             return outs
         caller = torch.cuda.current_stream()
         # every lazily packed weight is produced here, on the caller's stream, before the fork: a side
@@ -170,10 +279,12 @@ class ClipColorizer:
                                    for _ in range(lookahead - len(self._side_streams))]
         cur = self._main_stream
         side = self._side_streams[:lookahead]
+        T = len(frames_lab)
+        if use_graph:
+            return self._clip_graph(frames_lab, prev, caller, cur, side, on_frame)
         for s in side + [cur]:
             s.wait_stream(caller)       # inputs, weights and the exemplar cache were produced on the caller's stream
         fronts = {}
-        T = len(frames_lab)
         nb = max(1, int(front_batch))
         if isinstance(self.ex_cache, tuple) and isinstance(self.ex_cache[0], tuple):
             nb = 1                      # (the bf16 candidate-filter correlation takes one image per call)
@@ -182,7 +293,7 @@ class ClipColorizer:
         def launch_front(bi):
             s = side[bi % lookahead]
             with torch.cuda.stream(s):
-                fr = [frames_lab[t].detach().contiguous().float() for t in batches[bi]]
+                fr = [frames_lab[t] for t in batches[bi]]
                 IA_lab = fr[0] if len(fr) == 1 else torch.cat(fr, dim=0)
                 warped, sim, _ = warp_color(IA_lab[:, 0:1], self.IB_lab, self.features_B, self.vgg, self.warp,
                                             self.col, 0, temperature=self.temperature,
@@ -201,17 +312,83 @@ class ClipColorizer:
             for j, t in enumerate(members):
                 IA_lab, warped, sim = IA_b[j:j + 1], warped_b[j:j + 1], sim_b[j:j + 1]
                 with torch.cuda.stream(cur):
-                    color_input = ops.pack_color_input(IA_lab, warped, sim, last.detach().contiguous().float())
-                    ab = self.col(color_input)
-                    last = torch.cat((IA_lab[:, 0:1], ab), dim=1)
+                    ab = self.col(ops.pack_color_input(IA_lab, warped, sim, **prev))
+                    prev = dict(last_l=frames_lab[t], last_ab=ab)
                     if on_frame is not None:
                         on_frame(t, IA_lab, ab)
                 outs.append(ab)
                 if j == 0 and bi + lookahead < len(batches):   # (issued after the critical-path launches of the frame)
                     launch_front(bi + lookahead)
+        with torch.cuda.stream(cur):
+            last = torch.cat((frames_lab[-1][:, 0:1], outs[-1]), dim=1)     # test.py:96, once per call
         caller.wait_stream(cur)
         for x in outs + [last]:
             x.record_stream(caller)     # allocated on the recurrence stream, handed to the caller's stream
+        self.last_lab = last
+        return outs
+
+    def _clip_graph(self, frames_lab, prev, caller, cur, side, on_frame):
+        """clip() with captured launch sequences: per frame, the side stream copies the frame into its slot's static input
+        and replays the front-end graph; the recurrence stream packs the 7-channel input from the slot's outputs and runs the
+        ColorVidNet chain (launched kernel by kernel by default, see `graph_parts`; replayed, its prediction cloned out of
+        the graph's arena, otherwise).  Hazards the eager path leaves to the
+        allocator are explicit here: a slot's outputs must have been read (event `consumed`, recorded after the pack) before
+        the slot's next replay overwrites them; `cin` and `ab` are reused in stream order on the recurrence stream."""
+        T, L = len(frames_lab), len(side)
+        shape, dev = frames_lab[0].shape, frames_lab[0].device
+        for s in side + [cur]:
+            s.wait_stream(caller)
+        eager_front = self.graph_parts == "color"       # (experiments: tools/graph_overlap_probe.py)
+        eager_color = self.graph_parts == "front"
+        slots = [self._captured("front", shape, dev, i, side[i]) for i in range(L)]
+        chain = None if eager_color else self._captured("color", shape, dev, 0, self._capture_stream())
+        events = {}
+
+        def launch_front(t):
+            slot, s = slots[t % L], side[t % L]
+            with torch.cuda.stream(s):
+                if slot.consumed is not None:
+                    s.wait_event(slot.consumed)
+                slot.IA_in.copy_(frames_lab[t])
+                if eager_front:
+                    w_, s_, _ = warp_color(slot.IA_in[:, 0:1], self.IB_lab, None, self.vgg, self.warp, self.col, 0,
+                                           temperature=self.temperature, exemplar_cache=self.ex_cache)
+                    slot.warped.copy_(w_)
+                    slot.sim.copy_(s_)
+                else:
+                    slot.seq.replay()
+                ev = torch.cuda.Event()
+                ev.record(s)
+            events[t] = ev
+
+        for t in range(min(L, T)):
+            launch_front(t)
+        outs = []
+        for t in range(T):
+            slot = slots[t % L]
+            cur.wait_event(events.pop(t))
+            with torch.cuda.stream(cur):
+                cin = ops.pack_color_input(frames_lab[t], slot.warped, slot.sim, out=None if eager_color else chain.cin, **prev)
+                slot.consumed = torch.cuda.Event()
+                slot.consumed.record(cur)
+                if eager_color:
+                    ab = self.col(cin)
+                else:
+                    chain.seq.replay()
+                    ab = chain.ab.clone()
+                prev = dict(last_l=frames_lab[t], last_ab=ab)
+                if on_frame is not None:
+                    on_frame(t, frames_lab[t], ab)
+            outs.append(ab)
+            if t + L < T:
+                launch_front(t + L)
+        with torch.cuda.stream(cur):
+            last = torch.cat((frames_lab[-1][:, 0:1], outs[-1]), dim=1)
+        caller.wait_stream(cur)
+        for s in side:
+            caller.wait_stream(s)
+        for x in outs + [last]:
+            x.record_stream(caller)
         self.last_lab = last
         return outs
 

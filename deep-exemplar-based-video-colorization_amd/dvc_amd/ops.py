@@ -71,6 +71,10 @@ _autotune = _os.environ.get("DVC_AUTOTUNE", "0") == "1"
 _tuned = {}
 
 
+def autotune_enabled():
+    return _autotune
+
+
 def set_autotune(flag=True):
     global _autotune
     _autotune = bool(flag)
@@ -274,6 +278,10 @@ _conv_algo = _os.environ.get("DVC_CONV_ALGO", "auto")
 
 # conv -> InstanceNorm pairs: let the InstanceNorm launch sum the convolution's split-K partials (DVC_FUSE_REDUCE=0 disables)
 _fuse_reduce = _os.environ.get("DVC_FUSE_REDUCE", "1") == "1"
+
+
+def fuse_reduce():
+    return _fuse_reduce
 
 
 def set_fuse_reduce(flag=True):

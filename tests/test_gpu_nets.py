@@ -542,6 +542,80 @@ def test_clip_pipelined_equals_sequential():
         assert torch.equal(a, b)
 
 
+def test_graph_replay_equals_eager():
+    """hipGraph replay (dvc_amd/graph.py) of the per-frame launch sequences of test.py:68-96: the
+    captured front end and ColorVidNet chain, replayed through ClipColorizer.clip(graph=True) (pipelined, one graph per side
+    stream) and through the per-frame call ClipColorizer.frame(graph=True), give predictions BIT-IDENTICAL to the eager
+    launches — for every look-ahead depth, in both recurrence modes, when a call continues an earlier one, after the
+    exemplar is replaced (the captured front ends read the refreshed cache in place) and after a weight is reloaded (the
+    sequences are re-captured)."""
+    import contextlib
+    import io
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    from models.ColorVidNet import ColorVidNet
+    from models.NonlocalNet import VGG19_pytorch, WarpNet
+    dev = torch.device("cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        nets = (VGG19_pytorch(), WarpNet(1), ColorVidNet(7))
+    sds = (synth.vgg19_state_dict(0), synth.warpnet_state_dict(0), synth.colorvidnet_state_dict(0))
+    for m, sd in zip(nets, sds):
+        m.load_state_dict(sd)
+        m.eval().to(dev)
+    H, W = 48, 80
+    frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W).to(dev) for i in range(7)]
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).to(dev)
+    eager = ClipColorizer(*nets, temperature=1e-10)
+    eager.set_exemplar(IB)
+    cc = ClipColorizer(*nets, temperature=1e-10, graph=True)
+    cc.set_exemplar(IB)
+    for fp in (False, True):
+        ref = eager.clip(frames, lookahead=0, frame_propagate=fp)
+        for la in (0, 1, 2, 3):
+            got = cc.clip(frames, lookahead=la, frame_propagate=fp)
+            torch.cuda.synchronize()
+            assert len(got) == len(ref)
+            for t, (a, b) in enumerate(zip(got, ref)):
+                assert torch.equal(a, b), (fp, la, t)
+            assert torch.equal(cc.last_lab, eager.last_lab)
+    ref = eager.clip(frames, lookahead=0)
+    # replays do not alias their outputs: the predictions of one call survive the next call
+    keep = cc.clip(frames, lookahead=2)
+    cc.clip(list(reversed(frames)), lookahead=2)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(keep, ref))
+    # split the clip in two calls; per-frame API
+    first = cc.clip(frames[:3], lookahead=2)
+    rest = cc.clip(frames[3:], last=cc.last_lab, lookahead=2)
+    assert all(torch.equal(a, b) for a, b in zip(first + rest, ref))
+    last = torch.zeros_like(frames[0])
+    for t, f in enumerate(frames[:4]):
+        ab, nl = cc.frame(f, last)
+        ab_e, nl_e = eager.frame(f, last)
+        assert torch.equal(ab, ab_e) and torch.equal(nl, nl_e) and torch.equal(ab, ref[t])
+        last = torch.cat((f[:, 0:1], ab), dim=1)
+    n_graphs = len(cc._graphs)
+    # another exemplar of the same geometry: the captured sequences stay, the cache they read is refreshed in place
+    IB2 = synth.synth_lab(synth.EXEMPLAR_SEED + 5, H, W).to(dev)
+    eager.set_exemplar(IB2)
+    cc.set_exemplar(IB2)
+    ref2 = eager.clip(frames, lookahead=0)
+    got2 = cc.clip(frames, lookahead=2)
+    assert len(cc._graphs) == n_graphs and all(torch.equal(a, b) for a, b in zip(got2, ref2))
+    assert not torch.equal(ref2[0], ref[0])
+    # reloaded weights: packs change, the sequences are re-captured on the next call
+    sd2 = synth.colorvidnet_state_dict(3)
+    nets[2].load_state_dict(sd2)
+    ref3 = eager.clip(frames, lookahead=0)
+    got3 = cc.clip(frames, lookahead=2)
+    assert all(torch.equal(a, b) for a, b in zip(got3, ref3)) and not torch.equal(ref3[0], ref2[0])
+    # a graph-mode driver without an exemplar cache says so
+    with pytest.raises(RuntimeError, match="exemplar cache"):
+        bad = ClipColorizer(*nets, temperature=1e-10, cache_exemplar=False, graph=True)
+        bad.set_exemplar(IB)
+        bad.clip(frames[:2], lookahead=0)
+
+
 def test_luminance_noise_path(nets):
     """frame_colorization(luminance_noise=s) (models/FrameColor.py:55-57) adds s * randn to the L channel that feeds BOTH
     the VGG front end and ColorVidNet's first input channel: equal, bit for bit, to a call with the same noise already

@@ -37,6 +37,34 @@ for rep in range(3):
     t2 = time.perf_counter()
     print(f"3 frames: host issue {(t1 - t0) / 3 * 1e3:.2f} ms/frame, until the GPU is done {(t2 - t0) / 3 * 1e3:.2f} ms/frame "
           f"({n_conv} convolution launches per frame)", flush=True)
+# ---- the same through captured launch sequences (hipGraph replay, dvc_amd/graph.py): per-frame API and the clip driver
+ops.set_autotune(True)
+cg = ClipColorizer(*nets, graph=True)
+cg.set_exemplar(synth.synth_lab(2, H, W).to(dev))
+for i in range(4):
+    cg.frame(fr[i], last)
+cg.clip(fr, lookahead=2)
+cc.clip(fr, lookahead=2)
+torch.cuda.synchronize()
+for rep in range(3):
+    t0 = time.perf_counter()
+    for i in range(3):
+        ab, _ = cg.frame(fr[i], last)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"graph replay, 3 per-frame calls: host issue {(t1 - t0) / 3 * 1e3:.3f} ms/frame, until the GPU is done "
+          f"{(t2 - t0) / 3 * 1e3:.2f} ms/frame", flush=True)
+for name, drv in (("eager", cc), ("graph", cg)):
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        drv.clip(fr, lookahead=2)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"clip driver ({name}), 8 frames, look-ahead 2: host issue {(t1 - t0) / 8 * 1e3:.3f} ms/frame, until the GPU is done "
+              f"{(t2 - t0) / 8 * 1e3:.2f} ms/frame", flush=True)
 import cProfile, pstats
 pr = cProfile.Profile()
 torch.cuda.synchronize()
