@@ -48,6 +48,44 @@ __global__ __launch_bounds__(256) void corr_rowmean_kernel(const float* __restri
     if (threadIdx.x == 0) mean[blockIdx.x] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)P);
 }
 
+// float4 form (P % 4 == 0, aligned): workgroup = 32 positions (8 lanes x float4: one 128-byte line per channel row) x 32
+// channel groups — 162 workgroups at P = 5184 with 8 channels per thread and pass, where the scalar form below runs 81
+// workgroups of 64-deep serial loops (27 us for 10.6 MB: pure latency).
+__global__ __launch_bounds__(256) void corr_normalize_v4_kernel(const float* __restrict__ t, const float* __restrict__ mean,
+                                                                int C, int P, float eps, float* __restrict__ out) {
+    __shared__ float4 part[32][8];
+    const int px4 = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int p = (blockIdx.x * 8 + px4) * 4;
+    const int b = blockIdx.y;
+    const float* tb = t + (long)b * C * P;
+    const float* mb = mean + (long)b * C;
+    float* ob = out + (long)b * C * P;
+    const bool ok = p < P;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok)
+        for (int c = g; c < C; c += 32) {
+            const float4 v = *reinterpret_cast<const float4*>(tb + (long)c * P + p);
+            const float mu = mb[c];
+            const float a0 = v.x - mu, a1 = v.y - mu, a2 = v.z - mu, a3 = v.w - mu;
+            s.x = fmaf(a0, a0, s.x); s.y = fmaf(a1, a1, s.y); s.z = fmaf(a2, a2, s.z); s.w = fmaf(a3, a3, s.w);
+        }
+    part[g][px4] = s;
+    __syncthreads();
+    float4 tt = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const float4 v = part[k][px4];
+        tt.x += v.x; tt.y += v.y; tt.z += v.z; tt.w += v.w;
+    }
+    const float d0 = sqrtf(tt.x) + eps, d1 = sqrtf(tt.y) + eps, d2 = sqrtf(tt.z) + eps, d3 = sqrtf(tt.w) + eps;
+    if (ok)
+        for (int c = g; c < C; c += 32) {
+            const float4 v = *reinterpret_cast<const float4*>(tb + (long)c * P + p);
+            const float mu = mb[c];
+            *reinterpret_cast<float4*>(ob + (long)c * P + p) = make_float4((v.x - mu) / d0, (v.y - mu) / d1, (v.z - mu) / d2, (v.w - mu) / d3);
+        }
+}
+
 __global__ __launch_bounds__(256) void corr_normalize_kernel(const float* __restrict__ t,
                                                              const float* __restrict__ mean, int C, int P,
                                                              float eps, float* __restrict__ out) {
@@ -78,8 +116,11 @@ extern "C" int dvc_corr_prepare(const float* t_raw, int32_t B, int32_t C, int32_
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(corr_rowmean_kernel, dim3(B * C), dim3(256), 0, s, t_raw, P, mean_scratch);
     DVC_CHECK_LAUNCH("dvc_corr_prepare(mean)");
-    hipLaunchKernelGGL(corr_normalize_kernel, dim3(cdiv(P, 64), B), dim3(256), 0, s, t_raw, mean_scratch, C,
-                       P, eps, t_out);
+    if (P % 4 == 0 && (((reinterpret_cast<uintptr_t>(t_raw) | reinterpret_cast<uintptr_t>(t_out)) & 15) == 0))
+        hipLaunchKernelGGL(corr_normalize_v4_kernel, dim3(cdiv(P, 32), B), dim3(256), 0, s, t_raw, mean_scratch, C, P, eps, t_out);
+    else
+        hipLaunchKernelGGL(corr_normalize_kernel, dim3(cdiv(P, 64), B), dim3(256), 0, s, t_raw, mean_scratch, C,
+                           P, eps, t_out);
     DVC_CHECK_LAUNCH("dvc_corr_prepare(normalise)");
     return 0;
 }
@@ -167,11 +208,16 @@ __host__ __device__ __forceinline__ long corr_unit_owner(long u, long U, long G)
         CORR_CHAIN_LAST(MM);                                                                                \
     } while (0)
 
-// SOFT: the soft-temperature organisation of the softmax step (T >= 1e-3, see (4s) below) as its own instantiation — as a
-// run-time branch next to the sharp / exact paths it costs the production kernel 35 registers and 20 spills.
+// SOFT: the log2-domain organisations of the softmax step (see (4s) below) as their own instantiations — as a run-time
+// branch next to the sharp / exact paths they cost the production kernel 35 registers and 20 spills.
+//   1: soft temperatures, T >= 1e-3: p = exp2(f * c1 - m * log2 e), one fma + one v_exp_f32 per affinity;
+//   2: the middle regime 8.3e-9 <= T < 1e-3, where |f / T| reaches 1e8 and the fma form would cancel catastrophically:
+//      p = exp2((f - mf) * c1) with the running maximum mf kept in the AFFINITY domain (the difference of two nearby fp32
+//      affinities is exact or rounded at 6e-8 relative), one sub + one mul + one v_exp_f32 per affinity; the partial
+//      states then carry mf instead of m = fl32(mf / T) and the merge scales differences by c1 (CorrArgs::mscale).
 // DBG: the timeline / timing-experiment hooks (dvc_debug_corr_timeline, dvc_debug_corr_variant) as their own instantiation
 // too: their pointers and per-tile tests live in SGPRs the production kernel is short of.
-template <bool WTA, bool VEC4, bool SOFT = false, bool DBG = false>
+template <bool WTA, bool VEC4, int SOFT = 0, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     // two key tiles (double buffer, 2 x 32 KB) + three pooled-Lab tiles [3][256] (first 96 floats used).
     // Three, because with ONE barrier per iteration the pending tile's Lab (read during the chain by slow
@@ -284,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
     float mf = -INFINITY;    // running max affinity (after WTA / masking), exact
     float thr = -INFINITY;
     const float Tn = -a.T, ry = a.invT;
-    const bool sharp = !SOFT && 120.f * a.T < 1e-6f;   // wave-uniform: which organisation of step (4) pays
+    const bool sharp = !SOFT;   // (the launcher sends 120 T >= 1e-6 to the SOFT instantiations; (4b) is the sharp path's rare fallback)
     auto div_T = [&](float f) {
         float q = f * ry;
         q = fmaf(fmaf(Tn, q, f), ry, q);
@@ -318,8 +364,10 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         // wave-uniform tests, their state is never stored)
         if (__any(qvalid & (tmax > mf))) {
             const float mf_new = fmaxf(mf, tmax);
-            const float m_new = (mf_new == -INFINITY) ? -INFINITY : div_T(mf_new);   // (all keys masked so far)
-            const float sc = (mf == -INFINITY) ? 0.f : __expf(m - m_new);
+            // (SOFT 2: the state lives in the affinity domain, m == mf)
+            const float m_new = SOFT == 2 ? mf_new : (mf_new == -INFINITY) ? -INFINITY : div_T(mf_new);   // (-inf: all keys masked so far)
+            const float sc = (mf == -INFINITY) ? 0.f
+                             : SOFT == 2 ? __builtin_amdgcn_exp2f((mf - mf_new) * (ry * 1.44269504088896f)) : __expf(m - m_new);
             l *= sc;
             y0 *= sc;
             y1 *= sc;
@@ -373,13 +421,17 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
         // buys nothing there.  p = exp(f / T - m) as ONE fma + ONE v_exp_f32 per affinity (log2 domain), no guards (a
         // masked -inf gives exactly 0), and the arg-max bookkeeping once per tile instead of once per affinity:
         // 6 instead of ~18 VALU per affinity, the same cost class as the sharp path.
+        // (4m) the middle regime (SOFT == 2): the same step with p = exp2((f - mf) * c1).  The reference evaluates exp(s - max s)
+        // on s = fl32(f / T); here s is never formed — the two differ by the rounding of s, 6e-8 |f| in units of f, below the
+        // 3e-7 rounding of the affinities themselves (tests/test_gpu_ops.py: first-order bound, T = 1e-8 ... 9e-4).
         if (SOFT) {
             const float c1 = ry * 1.44269504088896f;
             const float nm2 = (mf == -INFINITY) ? 0.f : -m * 1.44269504088896f;
+            const float base = (mf == -INFINITY) ? 0.f : mf;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[r], c1, nm2));
+                const float pe = __builtin_amdgcn_exp2f(SOFT == 2 ? (sacc[r] - base) * c1 : fmaf(sacc[r], c1, nm2));
                 l += pe;
                 y0 = fmaf(pe, blp[kl], y0);
                 y1 = fmaf(pe, blp[CORR_KT + kl], y1);
@@ -472,7 +524,9 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
                     y2_o = __shfl_xor(y2, 32), f_o = __shfl_xor(fmax, 32);
         const int a_o = __shfl_xor(amax, 32);
         const float M = fmaxf(m, m_o);
-        const float s_a = (m == -INFINITY) ? 0.f : expf(m - M), s_b = (m_o == -INFINITY) ? 0.f : expf(m_o - M);
+        const float c1h = a.invT * 1.44269504088896f;
+        const float s_a = (m == -INFINITY) ? 0.f : SOFT == 2 ? __builtin_amdgcn_exp2f((m - M) * c1h) : expf(m - M);
+        const float s_b = (m_o == -INFINITY) ? 0.f : SOFT == 2 ? __builtin_amdgcn_exp2f((m_o - M) * c1h) : expf(m_o - M);
         l = fmaf(l_o, s_b, l * s_a);
         y0 = fmaf(y0_o, s_b, y0 * s_a);
         y1 = fmaf(y1_o, s_b, y1 * s_a);
@@ -507,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
 #define CORR_MQ 32
 #define CORR_MG 8
 __global__ __launch_bounds__(256) void corr_merge_kernel(const float* __restrict__ part, int nslot, int P,
-                                                         int nqb, int ntiles, long U, long G,
+                                                         int nqb, int ntiles, long U, long G, float mscale,
                                                          int h, int w, float* __restrict__ y_small,
                                                          float* __restrict__ sim_small,
                                                          float* __restrict__ y_up,
@@ -545,7 +599,9 @@ __global__ __launch_bounds__(256) void corr_merge_kernel(const float* __restrict
     for (int s = g; s < nused; s += CORR_MG) {
         const float* ps = pb + (long)s * CORR_NF * P;
         float ms = ps[0];
-        float sc = (ms == -INFINITY) ? 0.f : expf(ms - M);
+        // (mscale != 0: the states come from the middle-regime instantiation and carry the running maximum in the affinity
+        // domain; differences are scaled by log2(e) / T)
+        float sc = (ms == -INFINITY) ? 0.f : mscale != 0.f ? __builtin_amdgcn_exp2f((ms - M) * mscale) : expf(ms - M);
         L = fmaf(ps[(long)P], sc, L);
         Y0 = fmaf(ps[2L * P], sc, Y0);
         Y1 = fmaf(ps[3L * P], sc, Y1);
@@ -682,29 +738,39 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
     dim3 mgrid(cdiv(P, CORR_MQ), B);
     static_assert(CORR_QB % CORR_MQ == 0, "merge kernel assumes one query block per workgroup");
     const bool wta = wta_scale != 1.0f;
-    const bool soft = temperature >= 1e-3f;       // (4s): the training-side temperatures
+    // softmax organisation: 0 = sharp (guard window 120 T < 1e-6: one update per tile, exact division on the rare fallback),
+    // 1 = soft (T >= 1e-3, the training-side temperatures), 2 = the middle regime in between (log2 domain around the running
+    // maximum kept in the affinity domain)
+    const int mode = temperature >= 1e-3f ? 1 : (120.f * temperature >= 1e-6f ? 2 : 0);
+    const float mscale = mode == 2 ? a.invT * 1.44269504088896f : 0.f;
     auto launch = [&](bool wta_pass) {
+#define CORR_LAUNCH(W, V)                                                                                                  \
+        do {                                                                                                               \
+            if (mode == 1) hipLaunchKernelGGL((corr_fwd_kernel<W, V, 1>), grid, dim3(256), 0, s, a);                       \
+            else if (mode == 2) hipLaunchKernelGGL((corr_fwd_kernel<W, V, 2>), grid, dim3(256), 0, s, a);                  \
+            else hipLaunchKernelGGL((corr_fwd_kernel<W, V, 0>), grid, dim3(256), 0, s, a);                                 \
+        } while (0)
         if (wta_pass) {
-            if (vec4 && soft) hipLaunchKernelGGL((corr_fwd_kernel<true, true, true>), grid, dim3(256), 0, s, a);
-            else if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
-            else if (soft) hipLaunchKernelGGL((corr_fwd_kernel<true, false, true>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((corr_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
+            if (vec4) CORR_LAUNCH(true, true);
+            else CORR_LAUNCH(true, false);
         } else {
-            if (vec4 && soft) hipLaunchKernelGGL((corr_fwd_kernel<false, true, true>), grid, dim3(256), 0, s, a);
 #ifdef DVC_DEBUG
-            else if (vec4 && (a.dbg || a.dbg_variant)) hipLaunchKernelGGL((corr_fwd_kernel<false, true, false, true>), grid, dim3(256), 0, s, a);
+            if (vec4 && mode == 0 && (a.dbg || a.dbg_variant)) {
+                hipLaunchKernelGGL((corr_fwd_kernel<false, true, 0, true>), grid, dim3(256), 0, s, a);
+                return;
+            }
 #endif
-            else if (vec4) hipLaunchKernelGGL((corr_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
-            else if (soft) hipLaunchKernelGGL((corr_fwd_kernel<false, false, true>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((corr_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
+            if (vec4) CORR_LAUNCH(false, true);
+            else CORR_LAUNCH(false, false);
         }
+#undef CORR_LAUNCH
     };
     if (wta) {
         // pass 1: row maxima only (identical MFMA order => `f == rowmax` is exact in pass 2)
         launch(false);
         DVC_CHECK_LAUNCH("dvc_corr_fwd(pass1)");
         hipLaunchKernelGGL(corr_merge_kernel, mgrid, dim3(256), 0, s, a.part, a.nslot, P, pl.nqb, pl.ntiles, pl.U,
-                           pl.G, h, w, (float*)nullptr, fmax_buf, (float*)nullptr, (float*)nullptr, (int*)nullptr);
+                           pl.G, mscale, h, w, (float*)nullptr, fmax_buf, (float*)nullptr, (float*)nullptr, (int*)nullptr);
         DVC_CHECK_LAUNCH("dvc_corr_fwd(merge1)");
         launch(true);
     } else {
@@ -712,7 +778,7 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
     }
     DVC_CHECK_LAUNCH("dvc_corr_fwd");
     hipLaunchKernelGGL(corr_merge_kernel, mgrid, dim3(256), 0, s, a.part, a.nslot, P, pl.nqb, pl.ntiles, pl.U, pl.G,
-                       h, w, y_small, sim_small, y_up, sim_up, argmax);
+                       mscale, h, w, y_small, sim_small, y_up, sim_up, argmax);
     DVC_CHECK_LAUNCH("dvc_corr_fwd(merge)");
     return 0;
 }

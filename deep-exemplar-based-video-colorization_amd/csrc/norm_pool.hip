@@ -475,44 +475,8 @@ extern "C" int dvc_upsample_nearest(const float* x, int32_t planes, int32_t H, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// feature_normalize: per pixel, divide by the L2 norm over channels.  Workgroup = 64 pixels (16 lanes x
-// float4) x 16 channel groups: every load/store is a 256-byte row and 16 channel rows are in flight per
-// wave; the second pass re-reads from L2.
-__global__ __launch_bounds__(256) void channel_l2norm_v4_kernel(const float* __restrict__ x, int C, long HW,
-                                                                float eps, float* __restrict__ y) {
-    __shared__ float4 part[16][16];
-    const int px4 = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const long p = ((long)blockIdx.x * 16 + px4) * 4;
-    const int n = blockIdx.y;
-    const float* xn = x + (long)n * C * HW;
-    float* yn = y + (long)n * C * HW;
-    const bool ok = p < HW;  // HW % 4 == 0
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok)
-        for (int c = g; c < C; c += 16) {
-            const float4 v = *reinterpret_cast<const float4*>(xn + (long)c * HW + p);
-            s.x = fmaf(v.x, v.x, s.x);
-            s.y = fmaf(v.y, v.y, s.y);
-            s.z = fmaf(v.z, v.z, s.z);
-            s.w = fmaf(v.w, v.w, s.w);
-        }
-    part[g][px4] = s;
-    __syncthreads();
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const float4 v = part[k][px4];
-        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-    }
-    const float4 den = make_float4(sqrtf(t.x) + eps, sqrtf(t.y) + eps, sqrtf(t.z) + eps, sqrtf(t.w) + eps);
-    if (ok)
-        for (int c = g; c < C; c += 16) {
-            float4 v = *reinterpret_cast<const float4*>(xn + (long)c * HW + p);
-            v.x /= den.x; v.y /= den.y; v.z /= den.z; v.w /= den.w;
-            *reinterpret_cast<float4*>(yn + (long)c * HW + p) = v;
-        }
-}
-
+// feature_normalize: per pixel, divide by the L2 norm over channels (scalar form for maps whose H*W is not a multiple of 4;
+// the float4 form is channel_l2norm_multi_kernel below).
 __global__ __launch_bounds__(256) void channel_l2norm_kernel(const float* __restrict__ x, int C, long HW,
                                                              float eps, float* __restrict__ y) {
     __shared__ float part[4][64];
@@ -536,13 +500,89 @@ __global__ __launch_bounds__(256) void channel_l2norm_kernel(const float* __rest
         for (int c = g; c < C; c += 4) yn[(long)c * HW + p] = xn[(long)c * HW + p] / den;
 }
 
+// The four feature_normalize calls of a frame (FrameColor.py:16-23: relu2_1 .. relu5_1, 10.6 / 5.3 / 2.7 / 0.6 MB) as ONE
+// launch: separately they are 324 / 81 / 21 / 5 workgroups on 256 CUs — latency-bound, 62 us for 38 MB of traffic.
+// Workgroup = 32 pixels (8 lanes x float4: one 128-byte line per channel row) x 32 channel groups; the tensors' workgroup
+// ranges are concatenated (wg_start), so the small maps ride along with the large one.
+struct L2MultiArgs {
+    const float* x[DVC_L2NORM_MAX_TENSORS];
+    float* y[DVC_L2NORM_MAX_TENSORS];
+    int C[DVC_L2NORM_MAX_TENSORS], HW[DVC_L2NORM_MAX_TENSORS], wg_start[DVC_L2NORM_MAX_TENSORS + 1];
+    int count;
+    float eps;
+};
+__global__ __launch_bounds__(256) void channel_l2norm_multi_kernel(L2MultiArgs a) {
+    __shared__ float4 part[32][8];
+    int ti = 0;
+#pragma unroll
+    for (int k = 1; k < DVC_L2NORM_MAX_TENSORS; ++k) ti += (k < a.count && (int)blockIdx.x >= a.wg_start[k]) ? 1 : 0;
+    const int C = a.C[ti];
+    const long HW = a.HW[ti];
+    const int px4 = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const long p = ((long)(blockIdx.x - a.wg_start[ti]) * 8 + px4) * 4;
+    const int n = blockIdx.y;
+    const float* xn = a.x[ti] + (long)n * C * HW;
+    float* yn = a.y[ti] + (long)n * C * HW;
+    const bool ok = p < HW;  // HW % 4 == 0
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok)
+        for (int c = g; c < C; c += 32) {
+            const float4 v = *reinterpret_cast<const float4*>(xn + (long)c * HW + p);
+            s.x = fmaf(v.x, v.x, s.x);
+            s.y = fmaf(v.y, v.y, s.y);
+            s.z = fmaf(v.z, v.z, s.z);
+            s.w = fmaf(v.w, v.w, s.w);
+        }
+    part[g][px4] = s;
+    __syncthreads();
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const float4 v = part[k][px4];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    const float4 den = make_float4(sqrtf(t.x) + a.eps, sqrtf(t.y) + a.eps, sqrtf(t.z) + a.eps, sqrtf(t.w) + a.eps);
+    if (ok)
+        for (int c = g; c < C; c += 32) {
+            float4 v = *reinterpret_cast<const float4*>(xn + (long)c * HW + p);
+            v.x /= den.x; v.y /= den.y; v.z /= den.z; v.w /= den.w;
+            *reinterpret_cast<float4*>(yn + (long)c * HW + p) = v;
+        }
+}
+
+extern "C" int dvc_channel_l2norm_multi(const float* const* x, float* const* y, const int32_t* C, const int32_t* HW,
+                                        int32_t count, int32_t N, float eps, dvcStream stream) {
+    DVC_REQUIRE(x && y && C && HW && count > 0 && count <= DVC_L2NORM_MAX_TENSORS && N > 0, "dvc_channel_l2norm_multi: bad argument");
+    L2MultiArgs a;
+    a.count = count;
+    a.eps = eps;
+    int wgs = 0;
+    for (int i = 0; i < DVC_L2NORM_MAX_TENSORS; ++i) {
+        const int k = i < count ? i : count - 1;
+        a.x[i] = x[k]; a.y[i] = y[k]; a.C[i] = C[k]; a.HW[i] = HW[k];
+        a.wg_start[i] = wgs;
+        if (i < count) {
+            DVC_REQUIRE(x[i] && y[i] && C[i] > 0 && HW[i] > 0, "dvc_channel_l2norm_multi: bad tensor %d", i);
+            DVC_REQUIRE(HW[i] % 4 == 0 && (((reinterpret_cast<uintptr_t>(x[i]) | reinterpret_cast<uintptr_t>(y[i])) & 15) == 0),
+                        "dvc_channel_l2norm_multi: tensor %d needs H*W %% 4 == 0 and 16-byte aligned pointers (use dvc_channel_l2norm)", i);
+            wgs += cdiv(HW[i], 32);
+        }
+    }
+    a.wg_start[DVC_L2NORM_MAX_TENSORS] = wgs;
+    hipLaunchKernelGGL(channel_l2norm_multi_kernel, dim3(wgs, N), dim3(256), 0, (hipStream_t)stream, a);
+    DVC_CHECK_LAUNCH("dvc_channel_l2norm_multi");
+    return 0;
+}
+
 extern "C" int dvc_channel_l2norm(const float* x, int32_t N, int32_t C, int32_t HW, float eps, float* y,
                                   dvcStream stream) {
     DVC_REQUIRE(x && y && N > 0 && C > 0 && HW > 0, "dvc_channel_l2norm: bad argument");
     dim3 grid(cdiv(HW, 64), N);
     const bool v4 = (HW % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
-    if (v4) hipLaunchKernelGGL(channel_l2norm_v4_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, C, (long)HW, eps, y);
-    else hipLaunchKernelGGL(channel_l2norm_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, C, (long)HW, eps, y);
+    // (the float4 case IS the multi-tensor kernel with one tensor: a map normalised alone and the same map normalised in a
+    // group of four give the same bits)
+    if (v4) return dvc_channel_l2norm_multi(&x, &y, &C, &HW, 1, N, eps, stream);
+    hipLaunchKernelGGL(channel_l2norm_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, C, (long)HW, eps, y);
     DVC_CHECK_LAUNCH("dvc_channel_l2norm");
     return 0;
 }

@@ -65,6 +65,7 @@ SIGNATURES = {
     "dvc_avgpool4x4": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, _VP, _VP]),
     "dvc_upsample_nearest": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, c_i32, _VP, _VP]),
     "dvc_channel_l2norm": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP]),
+    "dvc_channel_l2norm_multi": (ctypes.c_int, [_VP, _VP, _VP, _VP, c_i32, c_i32, ctypes.c_float, _VP]),
     "dvc_gray2rgb": (ctypes.c_int, [_VP, c_i32, c_i32, c_i64, _VP, _VP]),
     "dvc_lab2rgb": (ctypes.c_int, [_VP, c_i32, c_i32, ctypes.c_float, _VP, _VP]),
     "dvc_pack_color_input": (ctypes.c_int, [_VP, c_i64, _VP, _VP, _VP, c_i64, _VP, c_i64, c_i32, c_i32, _VP, _VP]),

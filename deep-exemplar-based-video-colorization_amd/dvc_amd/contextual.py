@@ -21,7 +21,7 @@ import torch.nn as nn
 from . import _lib, ops
 from .ops import EPS64, _p, _stream
 
-ROW_BLOCK = 512
+ROW_BLOCK = 2048
 
 
 def _ip(t):
@@ -55,11 +55,12 @@ class _ContextualCX(torch.autograd.Function):
         R = min(ROW_BLOCK, (Nx + 63) // 64 * 64)
         hy, wy = (Y.shape[2], Y.shape[3]) if Y.dim() == 4 else (1, Ny)
         S = torch.empty((1, R, hy, wy), **f32)
+        blk = torch.zeros((C, R), **f32)                 # K-major block of Xn columns (one buffer for every block)
         for b in range(B):
             y_img = Yn[b].view(1, C, hy, wy)
             for i0 in range(0, Nx, R):
                 rows = min(R, Nx - i0)
-                _s_block(Xn[b], y_img, i0, rows, R, S)
+                _s_block(Xn[b], y_img, i0, rows, R, S, blk)
                 sl = slice(i0, i0 + rows)
                 _lib.check(lib.dvc_cx_rows(_p(S), rows, Ny, float(h), _p(a[b, sl]), _ip(jstar[b, sl]), _p(l[b, sl]), _p(r[b, sl]),
                                            _p(e[b, sl]), st), "dvc_cx_rows")
@@ -85,9 +86,12 @@ class _ContextualCX(torch.autograd.Function):
         dev = Xn.device
         f32 = dict(device=dev, dtype=torch.float32)
         st = _stream()
-        gout = gout.detach().float().cpu().tolist()            # B scalars (the loss is per sample)
+        # the incoming per-sample gradient is folded into the per-sample scale ON THE DEVICE (dvc_cx_ds multiplies the two):
+        # no host read-back, the backward pass only enqueues
+        gs = (gscale * gout.detach().to(gscale.dtype)).contiguous()
         R = min(ROW_BLOCK, (Nx + 63) // 64 * 64)
         S = torch.empty((1, R, hy, wy), **f32)
+        blk = torch.zeros((C, R), **f32)
         dST = torch.empty((1, Ny, R // 32, 32), **f32)                       # [Ny][R] as an image of R "pixels"
         tt, qq = (torch.empty(R, **f32), torch.empty(R, **f32)) if mode == 1 else (None, None)
         dXn = torch.empty_like(Xn)
@@ -96,14 +100,14 @@ class _ContextualCX(torch.autograd.Function):
             y_t = Yn[b].t().contiguous().view(Ny, 1, C)                      # K-major weights of d Xn = Yn dS^T
             for i0 in range(0, Nx, R):
                 rows = min(R, Nx - i0)
-                _s_block(Xn[b], y_img, i0, rows, R, S)
+                _s_block(Xn[b], y_img, i0, rows, R, S, blk)
                 sl = slice(i0, i0 + rows)
                 if mode == 1:
                     _lib.check(lib.dvc_cx_rows_tq(_p(S), _p(a[b, sl]), _p(l[b, sl]), _ip(cargi[b]), rows, Ny, i0, h, _p(tt), _p(qq),
                                                   st), "dvc_cx_rows_tq")
                 _lib.check(lib.dvc_cx_ds(_p(S), _p(a[b, sl]), _p(l[b, sl]), _p(r[b, sl]), _p(e[b, sl]), _ip(jstar[b, sl]),
-                                         None if cargi is None else _ip(cargi[b]), _p(tt), _p(qq), _p(gscale[b:b + 1]),
-                                         float(gout[b]), mode, rows, Ny, i0, R, h, None, _p(dST), st), "dvc_cx_ds")
+                                         None if cargi is None else _ip(cargi[b]), _p(tt), _p(qq), _p(gs[b:b + 1]),
+                                         1.0, mode, rows, Ny, i0, R, h, None, _p(dST), st), "dvc_cx_ds")
                 dxb = ops.conv2d(dST, y_t, None, ksize=1, pad=0)              # [1, C, R/32, 32]
                 dXn[b][:, i0:i0 + rows] = dxb.view(C, R)[:, :rows]
         dX = torch.empty_like(Xn)
@@ -111,11 +115,13 @@ class _ContextualCX(torch.autograd.Function):
         return dX.view(xshape), None, None, None, None
 
 
-def _s_block(Xn_b, y_img, i0, rows, R, S):
-    """S[i, :] = sum_c Xn[c, i0 + i] Yn[c, :] for a block of R rows (zero rows beyond `rows`), on the 1x1-conv engine."""
+def _s_block(Xn_b, y_img, i0, rows, R, S, blk):
+    """S[i, :] = sum_c Xn[c, i0 + i] Yn[c, :] for a block of R rows (zero rows beyond `rows`), on the 1x1-conv engine.
+    `blk` [C, R]: the caller's staging buffer for the block's columns (stream-ordered reuse, no allocation per block)."""
     C = Xn_b.shape[0]
-    blk = torch.zeros((C, R), device=Xn_b.device, dtype=torch.float32)
-    blk[:, :rows] = Xn_b[:, i0:i0 + rows]
+    if rows < R:
+        blk[:, rows:].zero_()
+    blk[:, :rows].copy_(Xn_b[:, i0:i0 + rows])
     ops.conv2d(y_img, blk.view(C, 1, R), None, ksize=1, pad=0, out=S)
 
 

@@ -21,7 +21,7 @@ import torch
 from . import _lib, ops
 from .ops import _p, _stream
 
-ROW_BLOCK = 512
+ROW_BLOCK = 2048
 
 
 class _FusedCorrelation(torch.autograd.Function):
@@ -54,6 +54,8 @@ class _FusedCorrelation(torch.autograd.Function):
         dS = torch.empty((1, R, h, w), device=dev, dtype=torch.float32)
         dST = torch.empty((1, P, R // 32, 32), device=dev, dtype=torch.float32)     # [P][R] as an image of R "pixels"
         lsum = torch.empty(2 * R, device=dev, dtype=torch.float32)      # row maxima and row sums of the recomputed block
+        th_blk = torch.zeros((C, R), device=dev, dtype=torch.float32)   # the block's theta columns, K-major ...
+        th_blk_t = torch.zeros((R, C), device=dev, dtype=torch.float32)  # ... and row-major (one pair of buffers for every block)
         for b in range(B):
             phi_img = phi[b].view(1, C, h, w)
             phi_t = phi[b].t().contiguous().view(P, 1, C)            # K-major weights of d theta = phi dS^T
@@ -62,8 +64,11 @@ class _FusedCorrelation(torch.autograd.Function):
             simb = sim[b].view(P)
             for i0 in range(0, P, R):
                 rows = min(R, P - i0)
-                th_blk = torch.zeros((C, R), device=dev, dtype=torch.float32)
-                th_blk[:, :rows] = theta[b][:, i0:i0 + rows]
+                if rows < R:
+                    th_blk[:, rows:].zero_()
+                    th_blk_t[rows:].zero_()
+                th_blk[:, :rows].copy_(theta[b][:, i0:i0 + rows])
+                th_blk_t[:rows].copy_(theta[b][:, i0:i0 + rows].t())
                 # F[i, :] = sum_c theta[c, i0 + i] phi[c, :]
                 ops.conv2d(phi_img, th_blk.view(C, 1, R), None, ksize=1, pad=0, out=F)
                 rc = lib.dvc_corr_softmax_bwd(
@@ -76,7 +81,7 @@ class _FusedCorrelation(torch.autograd.Function):
                 if rows < R:
                     dS.view(R, P)[rows:].zero_()
                 # d phi[c, j] += sum_i theta[c, i0 + i] dS[i, j]      (accumulated in place through the skip input)
-                ops.conv2d(dS, th_blk.t().contiguous().view(R, 1, C), None, ksize=1, pad=0, residual=dphi_img, out=dphi_img)
+                ops.conv2d(dS, th_blk_t.view(R, 1, C), None, ksize=1, pad=0, residual=dphi_img, out=dphi_img)
                 # d theta[c, i0 + i] = sum_j phi[c, j] dS[i, j]
                 dth = ops.conv2d(dST, phi_t, None, ksize=1, pad=0)          # [1, C, R/32, 32]
                 d_theta[b][:, i0:i0 + rows] = dth.view(C, R)[:, :rows]

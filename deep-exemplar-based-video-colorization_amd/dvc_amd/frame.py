@@ -18,9 +18,9 @@ def warp_color(IA_l, IB_lab, features_B, vggnet, nonlocal_net, colornet, feature
         B_relu1_1, B_relu2_1, B_relu3_1, B_relu4_1, B_relu5_1 = features_B
     # NOTE: output the feature before normalization (FrameColor.py:13-14)
     features_A = [A_relu1_1, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1]
-    nA = [feature_normalize(t) for t in features_A[1:]]
+    nA = ops.channel_l2norm_multi(features_A[1:])            # feature_normalize x4 (FrameColor.py:16-19), one launch
     if exemplar_cache is None:
-        nB = [feature_normalize(t) for t in (B_relu2_1, B_relu3_1, B_relu4_1, B_relu5_1)]
+        nB = ops.channel_l2norm_multi((B_relu2_1, B_relu3_1, B_relu4_1, B_relu5_1))
         nonlocal_BA_lab, similarity_map = nonlocal_net(IB_lab, *nA, *nB, temperature=temperature)
     else:
         # exemplar side cached: the B feature arguments are not read (pass the A ones as placeholders)
@@ -113,7 +113,6 @@ class ClipColorizer:
         self._side_streams = []
         self._main_stream = None
         self._tail_stream = None
-        self._graph_stream = None
         self._graphs = {}            # (kind, shape, slot) -> _FrontSlot / _ColorChain
 
     def prepare(self):
@@ -132,7 +131,7 @@ class ClipColorizer:
         old = self.ex_cache
         self.ex_cache = None
         if self.cache_exemplar:
-            nB = [feature_normalize(t) for t in self.features_B[1:]]
+            nB = ops.channel_l2norm_multi(self.features_B[1:])
             new = self.warp.exemplar_side(IB_lab, *nB, bf16=self.warp._use_bf16(self.temperature, 1))
             self.ex_cache = self._install_cache(old, new)
         return self.features_B
@@ -194,10 +193,24 @@ class ClipColorizer:
             self._graphs[key] = g
         return g
 
+    def _ensure_streams(self, lookahead):
+        """The recurrence stream (highest priority: the ColorVidNet chain is the critical path) and `lookahead` low-priority
+        side streams, created once and in this order."""
+        lo_prio, hi_prio = torch.cuda.Stream.priority_range()
+        if self._main_stream is None:
+            self._main_stream = torch.cuda.Stream(priority=hi_prio)
+        if len(self._side_streams) < lookahead:
+            self._side_streams += [torch.cuda.Stream(priority=lo_prio) for _ in range(lookahead - len(self._side_streams))]
+        return self._main_stream, self._side_streams[:lookahead]
+
     def _capture_stream(self):
-        if self._graph_stream is None:
-            self._graph_stream = torch.cuda.Stream()
-        return self._graph_stream
+        """Stream capture needs a non-default stream; it borrows a side stream instead of creating one of its own.  Measured
+        (bench.py on the MI355X, r03): with the per-frame sequences captured on a dedicated extra stream the pipelined driver
+        of the same process ran at 321 (eager launches) / 346 (front ends replayed) frames/s instead of 417 / 424 — the
+        three streams no longer overlapped.  Extra streams that merely exist and have run a kernel do not reproduce it, nor does
+        GPU_MAX_HW_QUEUES=8 change anything (profiles/r03_hw_queue_probe.txt); what inside the HIP runtime ties a graph to the
+        stream it was captured on was not isolated — the driver simply never creates that stream."""
+        return self._ensure_streams(2)[1][0]
 
     def frame(self, IA_lab, IA_last_lab, graph=None):
         """One frame_colorization call (the per-frame API of test.py:85): returns (ab, warped Lab)."""
@@ -270,15 +283,8 @@ class ClipColorizer:
         # every lazily packed weight is produced here, on the caller's stream, before the fork: a side
         # stream must never be the one that packs a weight another side stream reads (nets._PackCache)
         self.prepare()
-        lo_prio, hi_prio = torch.cuda.Stream.priority_range()
-        if self._main_stream is None:
-            # the ColorVidNet recurrence is the critical path: highest priority; the front ends fill in
-            self._main_stream = torch.cuda.Stream(priority=hi_prio)
-        if len(self._side_streams) < lookahead:
-            self._side_streams += [torch.cuda.Stream(priority=lo_prio)
-                                   for _ in range(lookahead - len(self._side_streams))]
-        cur = self._main_stream
-        side = self._side_streams[:lookahead]
+        # the ColorVidNet recurrence is the critical path: highest priority; the front ends fill in
+        cur, side = self._ensure_streams(lookahead)
         T = len(frames_lab)
         if use_graph:
             return self._clip_graph(frames_lab, prev, caller, cur, side, on_frame)

@@ -507,6 +507,28 @@ def channel_l2norm(x, eps=EPS64):
     return y
 
 
+def channel_l2norm_multi(xs, eps=EPS64):
+    """feature_normalize of several feature maps of one batch in ONE launch (dvc_channel_l2norm_multi); falls back to one
+    launch per map when a map's H*W is not a multiple of 4."""
+    lib = _lib.load()
+    xs = list(xs)
+    for i, x in enumerate(xs):
+        _need(x, f"x[{i}]")
+    N = xs[0].shape[0]
+    if len(xs) > 8 or any(x.shape[0] != N or (x.shape[2] * x.shape[3]) % 4 for x in xs):
+        return [channel_l2norm(x, eps) for x in xs]
+    ys = [torch.empty_like(x) for x in xs]
+    n = len(xs)
+    px = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+    py = (ctypes.c_void_p * n)(*[y.data_ptr() for y in ys])
+    cs = (ctypes.c_int32 * n)(*[x.shape[1] for x in xs])
+    hw = (ctypes.c_int32 * n)(*[x.shape[2] * x.shape[3] for x in xs])
+    _lib.check(lib.dvc_channel_l2norm_multi(ctypes.cast(px, ctypes.c_void_p), ctypes.cast(py, ctypes.c_void_p),
+                                            ctypes.cast(cs, ctypes.c_void_p), ctypes.cast(hw, ctypes.c_void_p), n, N,
+                                            float(eps), _stream()), "dvc_channel_l2norm_multi")
+    return ys
+
+
 def gray2rgb(l):
     """l: [N,1,H,W] (may be the channel-0 slice of a contiguous [N,3,H,W] Lab tensor)."""
     lib = _lib.load()

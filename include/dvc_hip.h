@@ -196,6 +196,13 @@ int dvc_upsample_nearest(const float* x, int32_t planes, int32_t H, int32_t W, i
 /* feature_normalize: x / (||x||_2 over C + eps), utils/util.py:155-158. */
 int dvc_channel_l2norm(const float* x, int32_t N, int32_t C, int32_t HW, float eps, float* y,
                        dvcStream stream);
+/* The same for up to DVC_L2NORM_MAX_TENSORS feature maps of one batch in ONE launch (FrameColor.py:16-23 normalises relu2_1 ..
+ * relu5_1 of a frame back to back; the small maps alone are a handful of workgroups each).  x / y / C / HW: host arrays of
+ * `count` entries; every map needs H*W % 4 == 0 and 16-byte aligned pointers.  Same arithmetic per pixel as
+ * dvc_channel_l2norm up to the summation order of the channel groups. */
+#define DVC_L2NORM_MAX_TENSORS 8
+int dvc_channel_l2norm_multi(const float* const* x, float* const* y, const int32_t* C, const int32_t* HW,
+                             int32_t count, int32_t N, float eps, dvcStream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Colour / glue elementwise ops.

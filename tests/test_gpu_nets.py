@@ -579,6 +579,11 @@ def test_graph_replay_equals_eager():
                 assert torch.equal(a, b), (fp, la, t)
             assert torch.equal(cc.last_lab, eager.last_lab)
     ref = eager.clip(frames, lookahead=0)
+    # every choice of what the pipelined driver replays (default "front": see ClipColorizer.graph_parts)
+    for parts in ("all", "color", "front"):
+        cc.graph_parts = parts
+        got = cc.clip(frames, lookahead=2)
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), parts
     # replays do not alias their outputs: the predictions of one call survive the next call
     keep = cc.clip(frames, lookahead=2)
     cc.clip(list(reversed(frames)), lookahead=2)

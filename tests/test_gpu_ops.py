@@ -381,6 +381,21 @@ def test_pools_upsample_l2norm(ops):
     assert (ops.channel_l2norm(f.cuda()).double().cpu() - ref).abs().max().item() < 1e-6
 
 
+def test_channel_l2norm_multi(ops):
+    """feature_normalize (utils/util.py:155-158) of relu2_1 .. relu5_1 in one launch: every map against the oracle (fp64 norm)
+    and bit-identical to the map normalised alone; maps whose H*W is not a multiple of 4 take the per-map launches."""
+    from oracle import dvc_oracle as O
+    g = torch.Generator().manual_seed(5)
+    for shapes in ([(2, 128, 12, 20), (2, 256, 6, 10), (2, 512, 3, 8), (2, 512, 2, 2)], [(1, 64, 5, 5), (1, 8, 4, 4)],
+                   [(1, 128, 108, 192), (1, 256, 54, 96), (1, 512, 27, 48), (1, 512, 13, 24)]):
+        xs = [torch.randn(*sh, generator=g) * 3 for sh in shapes]
+        got = ops.channel_l2norm_multi([x.cuda() for x in xs])
+        for x, y in zip(xs, got):
+            ref = O.feature_normalize(x.double())
+            assert (y.double().cpu() - ref).abs().max().item() < 2e-7
+            assert torch.equal(y, ops.channel_l2norm(x.cuda()))
+
+
 def test_colour_glue(ops):
     from dvc_amd import synth
     from oracle import dvc_oracle as O
