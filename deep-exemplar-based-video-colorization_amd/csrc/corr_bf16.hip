@@ -183,14 +183,17 @@ __global__ __launch_bounds__(256, 2) void corr_bf16_kernel(CorrBf16Args a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&u), qf[s], acc, 0, 0, 0);
         }
         const int k0 = t * CB_KT;
-        float tilemax = -INFINITY;
+        if (k0 + CB_KT > P) {          // partial last tile only (wave-uniform): keys beyond P never win
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float f = key < P ? acc[r] : -INFINITY;
-            acc[r] = f;
-            tilemax = fmaxf(tilemax, f);
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                acc[r] = key < P ? acc[r] : -INFINITY;
+            }
         }
+        const float tm0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]), tm1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
+        const float tm2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]), tm3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
+        const float tm4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
+        const float tilemax = fmaxf(fmaxf(fmaxf(tm0, tm1), fmaxf(tm2, tm3)), fmaxf(tm4, acc[15]));
         if (PASS == 1) {
             lmax = fmaxf(lmax, tilemax);
         } else if (tilemax >= thr) {  // rare: some key of this lane is within DELTA of the row maximum
@@ -208,14 +211,16 @@ __global__ __launch_bounds__(256, 2) void corr_bf16_kernel(CorrBf16Args a) {
     if (PASS == 1 && qvalid) a.part_max[((long)b * a.nslot + split * 2 + hi) * P + query] = lmax;
 }
 
+// row maximum over the partial maxima of pass 1; also clears the candidate counter pass 2 appends to
 __global__ __launch_bounds__(256) void corr_bf16_max_kernel(const float* __restrict__ part, int nslot, int P,
-                                                            float* __restrict__ row_max) {
+                                                            float* __restrict__ row_max, int* __restrict__ cnt) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (q >= P) return;
     float m = -INFINITY;
     for (int s = 0; s < nslot; ++s) m = fmaxf(m, part[((long)b * nslot + s) * P + q]);
     row_max[(long)b * P + q] = m;
+    cnt[(long)b * P + q] = 0;
 }
 
 // one wave per query: exact fp32 re-scoring of the candidates + max / softmax / colour gather
@@ -287,7 +292,21 @@ __global__ __launch_bounds__(256) void corr_bf16_rescore_kernel(const float* __r
                 const bool lower = ((lane & j) == 0);
                 key = (lower == up) ? min(key, other) : max(key, other);
             }
-        if (lane < n) accumulate(key, score(key));
+        // The exact fp32 affinity of candidate i, by the WHOLE wave: lane c4 multiplies channels 4 c4 .. 4 c4 + 3 (one
+        // coalesced 1 KB row of phi, the query's four channels from LDS), then a fixed xor tree adds the 64 partial sums —
+        // a handful of candidates per query, each one load deep, instead of one lane walking a 256-channel row on its own
+        // (64 dependent uncoalesced loads).  Lane i keeps candidate i's affinity; the softmax below is unchanged.
+        const float4 qv = *reinterpret_cast<const float4*>(&qs[wave][lane * 4]);
+        float fmine = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const int k = __shfl(key, i, 64);
+            const float4 kv = *reinterpret_cast<const float4*>(pb + (long)k * CB_C + lane * 4);
+            float f = fmaf(qv.w, kv.w, fmaf(qv.z, kv.z, fmaf(qv.y, kv.y, qv.x * kv.x)));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) f += __shfl_xor(f, off, 64);
+            fmine = lane == i ? f : fmine;
+        }
+        if (lane < n) accumulate(key, fmine);
     } else {
         for (int k = lane; k < P; k += 64) accumulate(k, score(k));
     }
@@ -383,10 +402,8 @@ extern "C" int dvc_corr_fwd_bf16(const void* theta_bf16_pc, const void* phi_bf16
     dim3 grid(cdiv(P, CB_QB), nsplit, B);
     hipLaunchKernelGGL(corr_bf16_kernel<1>, grid, dim3(256), 0, s, a);
     DVC_CHECK_LAUNCH("dvc_corr_fwd_bf16(pass1)");
-    hipLaunchKernelGGL(corr_bf16_max_kernel, dim3(cdiv(P, 256), B), dim3(256), 0, s, a.part_max, a.nslot, P, row_max);
+    hipLaunchKernelGGL(corr_bf16_max_kernel, dim3(cdiv(P, 256), B), dim3(256), 0, s, a.part_max, a.nslot, P, row_max, a.cnt);
     DVC_CHECK_LAUNCH("dvc_corr_fwd_bf16(max)");
-    hipError_t e = hipMemsetAsync(a.cnt, 0, sizeof(int) * n, s);
-    DVC_REQUIRE(e == hipSuccess, "dvc_corr_fwd_bf16: hipMemsetAsync: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(corr_bf16_kernel<2>, grid, dim3(256), 0, s, a);
     DVC_CHECK_LAUNCH("dvc_corr_fwd_bf16(pass2)");
     hipLaunchKernelGGL(corr_bf16_rescore_kernel, dim3(cdiv(P, 4), B), dim3(256), 0, s, theta_f32_pc, phi_f32_pc, blab,

@@ -131,7 +131,19 @@ def load():
     return lib
 
 
+# DVC_SYNC_DEBUG=1: synchronise after every library call and name it on stderr first — an asynchronous GPU memory fault is
+# then reported right after the call that caused it (debugging only: it serialises everything)
+_SYNC_DEBUG = os.environ.get("DVC_SYNC_DEBUG", "0") == "1"
+
+
 def check(rc, what=""):
+    if _SYNC_DEBUG:
+        import sys
+        import torch
+        sys.stderr.write(f"[dvc] {what}\n")
+        sys.stderr.flush()
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()
     if rc != 0:
         msg = load().dvc_last_error().decode(errors="replace")
         raise RuntimeError(f"libdvc_hip {what} failed: {msg}")
