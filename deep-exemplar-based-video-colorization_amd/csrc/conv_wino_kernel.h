@@ -421,7 +421,13 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
                     v0 = apply_act(v0, a.act, slope);
                     v1 = apply_act(v1, a.act, slope);
                 }
-                if (pairst) {
+                if (pairst && VAR == 2) {
+                    // write-through (sc1) stores: the lines leave the XCD's L2 while the kernel runs instead of in the
+                    // end-of-kernel release (A/B only, tools/conv_wino_ab.py)
+                    union { float2 f; unsigned long long u; } cv;
+                    cv.f = make_float2(v0, v1);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(yb + row + ox0), cv.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (pairst) {
                     *reinterpret_cast<float2*>(yb + row + ox0) = make_float2(v0, v1);
                 } else {
                     if (okx0) yb[row + ox0] = v0;
@@ -439,6 +445,15 @@ template <int WM, int WN, int KC>
 static void conv_wino_launch_shape(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s) {
     constexpr int NT = 128 * WM * WN;
 #ifdef DVC_DEBUG
+    if (s.k.dbg & 32) {     // dvc_debug_conv_variant(32): write-through output stores (A/B only)
+        switch (tr) {
+            case 1: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 1, KC, 2>), grid, dim3(NT), 0, st, s); break;
+            case 2: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 2, KC, 2>), grid, dim3(NT), 0, st, s); break;
+            case 4: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 4, KC, 2>), grid, dim3(NT), 0, st, s); break;
+            default: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 8, KC, 2>), grid, dim3(NT), 0, st, s); break;
+        }
+        return;
+    }
     if (s.k.dbg & 16) {     // dvc_debug_conv_variant(16): scalar transform arithmetic (A/B only)
         switch (tr) {
             case 1: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 1, KC, 1>), grid, dim3(NT), 0, st, s); break;

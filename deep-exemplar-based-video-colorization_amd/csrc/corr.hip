@@ -685,7 +685,12 @@ extern "C" size_t dvc_corr_workspace_bytes(int32_t B, int32_t P) {
 static long long* g_corr_dbg = nullptr;
 static int g_corr_dbg_tiles = 0;
 static int g_corr_dbg_variant = 0;
+long long* g_corr_bf16_dbg = nullptr;     // (max_tiles < 0: the buffer is for the bf16 pass kernels instead, [2][256] stamps)
 extern "C" void dvc_debug_corr_timeline(long long* buf, int max_tiles) {
+    if (max_tiles < 0) {
+        g_corr_bf16_dbg = buf;
+        return;
+    }
     g_corr_dbg = buf;
     g_corr_dbg_tiles = max_tiles;
 }

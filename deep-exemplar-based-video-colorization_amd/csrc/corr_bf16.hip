@@ -11,10 +11,13 @@
 // softmax weight is <= exp(-4e-3 / T): negligible (< 4e-18) for T <= 1e-4 — the regime test.py:94 uses
 // (T = 1e-10).  For larger temperatures the host falls back to the fp32 kernel.
 //
-//   pass 1  corr_bf16_kernel<1>   v_mfma_f32_32x32x16_bf16, per-lane running max of its keys
-//           corr_bf16_max_kernel  row maximum over the partial maxima
-//   pass 2  corr_bf16_kernel<2>   same MFMAs again (they are ~16x cheaper than fp32 ones), keys within
-//                                 DELTA of the row maximum are appended to a per-query candidate list
+//   pass 1  corr_bf16_kernel<1>   v_mfma_f32_32x32x16_bf16, per-lane running max of its keys (partial maxima per key split)
+//   pass 2  corr_bf16_kernel<2>   same MFMAs again (they are ~16x cheaper than fp32 ones); every wave first takes its
+//                                 queries' row maxima from pass 1's partial maxima, then keys within DELTA of the row
+//                                 maximum are appended to a per-query candidate list
+//   (both passes: a ring of four 16 KB key tiles filled by LDS-DMA three tiles ahead, hand-placed vmcnt / lgkmcnt waits —
+//   at 16 MFMAs of 32 cycles per tile the kernel is bound by the L2 / fabric latency and bandwidth of the key stream:
+//   256 workgroups of 256 queries x (13.5 key tiles x 16 KB + 128 KB of theta) = 87 MB per pass at P = 5184)
 //   rescore corr_bf16_rescore_kernel  one wave per query: exact fp32 dot products of the (sorted)
 //                                 candidates, then the reference's max / softmax(f/T) / colour gather
 //                                 restricted to them; a query whose list overflowed is re-scored
@@ -27,10 +30,12 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define CB_C 256
 #define CB_KT 32          // keys per LDS tile (32 x 512 B = 16 KB)
-#define CB_QB 128         // queries per workgroup
+#define CB_QB 256         // queries per workgroup: 8 waves x 32 (one workgroup per CU, two waves per SIMD); a key tile
+                          // fetched once serves 256 queries — the passes are bound by the key stream, not the matrix pipe
 #define CB_CAP 64         // candidate list capacity per query (one per lane of the re-scoring wave)
 #define CB_DELTA 7.9e-3f  // 2 * 2^-8 + margin
 
@@ -119,18 +124,40 @@ struct CorrBf16Args {
     const unsigned short* theta;  // [B][P][C] bf16
     const unsigned short* phi;    // [B][P][C] bf16
     float* part_max;              // pass 1 out: [B][nslot][P]
-    const float* row_max;         // pass 2 in:  [B][P]
     int* cnt;                     // pass 2 out: [B][P]
     int* list;                    // pass 2 out: [B][P][CB_CAP]
     int P, ntiles, tiles_per_split, nslot;
+    long long* dbg;               // -DDVC_DEBUG only: s_memtime stamps of wave 0 of workgroup 0 (dvc_debug_corr_timeline)
 };
 
+// LDS fragment reads as inline assembly: a ds_read the compiler can see makes it drain the LDS-DMA queue first
+// (`s_waitcnt vmcnt(0)`: the reads may alias the DMA destinations), which would serialise the key-tile prefetch with the
+// arithmetic — with 16 MFMAs of 32 cycles per tile against ~2000 cycles of L2 / fabric latency per tile fetch, the r02 form
+// of this kernel (one tile in flight, compiler-visible reads) spent 8x the matrix time per tile.  The waits are placed by hand.
+#define CB_RD8(F, A, S0)                                                                                                 \
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"           \
+                 "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"               \
+                 : "=&v"(F[S0 + 0]), "=&v"(F[S0 + 1]), "=&v"(F[S0 + 2]), "=&v"(F[S0 + 3]), "=&v"(F[S0 + 4]), "=&v"(F[S0 + 5]),    \
+                   "=&v"(F[S0 + 6]), "=&v"(F[S0 + 7])                                                                     \
+                 : "v"(A[S0 + 0]), "v"(A[S0 + 1]), "v"(A[S0 + 2]), "v"(A[S0 + 3]), "v"(A[S0 + 4]), "v"(A[S0 + 5]),        \
+                   "v"(A[S0 + 6]), "v"(A[S0 + 7])                                                                         \
+                 : "memory")
+#define CB_WAIT8(F, S0, N)                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                              \
+                 : "+v"(F[S0 + 0]), "+v"(F[S0 + 1]), "+v"(F[S0 + 2]), "+v"(F[S0 + 3]), "+v"(F[S0 + 4]), "+v"(F[S0 + 5]),  \
+                   "+v"(F[S0 + 6]), "+v"(F[S0 + 7])                                                                       \
+                 :                                                                                                        \
+                 : "memory")
+
+#define CB_NBUF 4         // key tiles in the LDS ring: tile t is consumed while t+1 .. t+3 are in flight
+
 template <int PASS>
-__global__ __launch_bounds__(256, 2) void corr_bf16_kernel(CorrBf16Args a) {
-    // two key tiles [32 keys][32 x 16 B], 16-byte columns XOR-swizzled with (key & 15) so that the
-    // per-lane ds_read_b128 of column 2s+hi over 32 different keys is bank-conflict free
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * CB_KT * CB_C];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(512, 2) void corr_bf16_kernel(CorrBf16Args a) {
+    // ring of four key tiles [32 keys][32 x 16 B], 16-byte columns XOR-swizzled with (key & 15) so that the per-lane
+    // ds_read_b128 of column 2s+hi over 32 different keys is bank-conflict free; eight such slots (128 KB: one workgroup per
+    // CU) so that the prologue can stage every wave's theta block in its own slot
+    __shared__ __attribute__((aligned(16))) unsigned short smem[8 * CB_KT * CB_C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, split = blockIdx.y;
     const int P = a.P;
@@ -138,23 +165,20 @@ __global__ __launch_bounds__(256, 2) void corr_bf16_kernel(CorrBf16Args a) {
     const bool qvalid = query < P;
     const unsigned short* th = a.theta + (long)b * P * CB_C;
     const unsigned short* ph = a.phi + (long)b * P * CB_C;
-
-    // query fragments: B[k = 16s + 8hi .. +7][j = l31]
-    bf16x8 qf[CB_C / 16];
-#pragma unroll
-    for (int s = 0; s < CB_C / 16; ++s) {
-        uint4 u = qvalid ? *reinterpret_cast<const uint4*>(th + (long)query * CB_C + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
-        qf[s] = *reinterpret_cast<bf16x8*>(&u);
-    }
     const int t0 = split * a.tiles_per_split;
     const int t1 = min(a.ntiles, t0 + a.tiles_per_split);
+    long long* dbgp = nullptr;
+    int dbgi = 0;
+    if (kDvcDebug && a.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) dbgp = a.dbg + (PASS - 1) * 256;
+#define CB_STAMP() do { if (kDvcDebug && dbgp && dbgi < 255) dbgp[dbgi++] = __builtin_amdgcn_s_memtime(); } while (0)
+    CB_STAMP();
 
-    auto issue = [&](int t, int buf) {  // LDS-DMA: a wave instruction moves 2 keys x 512 B
+    auto issue = [&](int t, int buf) {  // LDS-DMA: a wave instruction moves 2 keys x 512 B; 2 instructions per wave and tile
         const int k0 = t * CB_KT;
         unsigned short* kb = smem + buf * CB_KT * CB_C;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = i * 4 + wave;                       // 1 KB chunk = keys 2c, 2c+1
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * 8 + wave;                       // 1 KB chunk = keys 2c, 2c+1
             const int row = 2 * c + (lane >> 5), cp = lane & 31;  // LDS (row, 16-byte column cp)
             const int col = cp ^ (row & 15);                  // ... holds data column col
             const int key = k0 + row < P ? k0 + row : 0;      // beyond P: any valid row (masked later)
@@ -162,26 +186,107 @@ __global__ __launch_bounds__(256, 2) void corr_bf16_kernel(CorrBf16Args a) {
             __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(kb + c * 512), 16, 0, 0);
         }
     };
+    // LDS byte offsets of the lane's 16 fragments inside a tile (loop-invariant)
+    unsigned foff[CB_C / 16];
+#pragma unroll
+    for (int s = 0; s < CB_C / 16; ++s) foff[s] = (unsigned)(l31 * CB_C * 2 + (((2 * s + hi) ^ (l31 & 15)) * 16));
+    const unsigned smem_base = (unsigned)(size_t)(AS3 unsigned short*)smem;
+
+    // query fragments B[k = 16s + 8hi .. +7][j = l31].  A wave's 32 queries are ONE contiguous 16 KB block of the [P][C] array:
+    // it is staged like a key tile (16 coalesced 1 KB LDS-DMA pieces into the wave's own slot, same swizzle) and the
+    // fragments are read back with the key tiles' conflict-free pattern.  The direct form — every lane fetching its 16-byte
+    // pieces at a 512-byte stride — touched 32 different 128-byte lines per wave instruction, four times each over the 16
+    // pieces, with 128 KB per workgroup thrashing the 32 KB L1: the theta prologue, not the tile loop, was most of the pass.
+    bf16x8 qf[CB_C / 16];
+    {
+        unsigned short* tbuf = smem + wave * CB_KT * CB_C;
+        const int q0 = blockIdx.x * CB_QB + wave * 32;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int row = 2 * c + (lane >> 5), cp = lane & 31;
+            const int col = cp ^ (row & 15);
+            const int q = q0 + row < P ? q0 + row : 0;        // beyond P: a valid row; such lanes never store / never match
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(th + (long)q * CB_C + col * 8), (AS3 void*)(tbuf + c * 512), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the wave reads only what it fetched itself
+        unsigned fa[CB_C / 16];
+        const unsigned tb = smem_base + (unsigned)wave * (CB_KT * CB_C * 2);
+#pragma unroll
+        for (int s = 0; s < CB_C / 16; ++s) fa[s] = tb + foff[s];
+        u32x4 fr[CB_C / 16];
+        CB_RD8(fr, fa, 0);
+        CB_RD8(fr, fa, 8);
+        CB_WAIT8(fr, 0, 8);
+        CB_WAIT8(fr, 8, 0);
+#pragma unroll
+        for (int s = 0; s < CB_C / 16; ++s) qf[s] = *reinterpret_cast<bf16x8*>(&fr[s]);
+    }
+    CB_STAMP();
+    __builtin_amdgcn_s_barrier();             // every wave has its fragments: slots 0 .. 3 become the key-tile ring
+    CB_STAMP();
+#pragma unroll
+    for (int d = 0; d < CB_NBUF - 1; ++d)
+        if (t0 + d < t1) issue(t0 + d, d);
 
     float lmax = -INFINITY;
     float thr = 0.f;
-    if (PASS == 2) thr = (qvalid ? a.row_max[(long)b * P + query] : INFINITY) - CB_DELTA;
-
-    if (t0 < t1) issue(t0, 0);
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-        const int cur = (t - t0) & 1;
-        issue(min(t + 1, t1 - 1), cur ^ 1);
-        const unsigned short* kb = smem + cur * CB_KT * CB_C + l31 * CB_C;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < CB_C / 16; ++s) {
-            const int cp = (2 * s + hi) ^ (l31 & 15);
-            uint4 u = *reinterpret_cast<const uint4*>(kb + cp * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&u), qf[s], acc, 0, 0, 0);
+    // pass 2: the lane's candidate keys (almost always none or one) stay in registers and are appended after the loop — an
+    // atomic with return inside the loop makes the wave drain its three tiles in flight and holds the other seven at the barrier
+    int ck0 = 0, ck1 = 0, ck2 = 0, ck3 = 0, cn = 0;
+    if (PASS == 2) {
+        // row maximum over the partial maxima of pass 1, stored [query][slot]: a lane's nslot values are contiguous (one or two
+        // cache lines; as [slot][query] the ~24 loads of a lane hit 24 different lines and this prologue took 15 k cycles)
+        float rm = -INFINITY;
+        if (qvalid) {
+            const float* pm = a.part_max + ((long)b * P + query) * a.nslot;
+            for (int s = 0; s < a.nslot; ++s) rm = fmaxf(rm, pm[s]);
         }
+        thr = (qvalid ? rm : INFINITY) - CB_DELTA;
+    }
+    // Everything issued so far has to be there before the first tile anyway (the tile fetches are the oldest operations and
+    // VMEM returns in order).  The wait is a BUILTIN so that the compiler's own wait-count bookkeeping sees it: with the theta
+    // loads still pending in its model it puts `s_waitcnt vmcnt(0)` in front of the loop's first MFMA — on every iteration,
+    // draining the three tiles in flight.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) expcnt(7) lgkmcnt(15)
+    CB_STAMP();
+    for (int t = t0; t < t1; ++t) {
+        const int cur = (t - t0) & (CB_NBUF - 1);
+        // tile t has landed once at most the 2-instruction fetches of the tiles after it are outstanding
+        if (t + 2 < t1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (t + 1 < t1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CB_STAMP();
+        __builtin_amdgcn_s_barrier();        // ... for every wave's pieces; and every wave is done reading tile t-1
+        CB_STAMP();
+        if (t + CB_NBUF - 1 < t1) issue(t + CB_NBUF - 1, (cur + CB_NBUF - 1) & (CB_NBUF - 1));   // into tile t-1's buffer
+        unsigned fa[CB_C / 16];
+        const unsigned tb = smem_base + (unsigned)cur * (CB_KT * CB_C * 2);
+#pragma unroll
+        for (int s = 0; s < CB_C / 16; ++s) fa[s] = tb + foff[s];
+        u32x4 fr[CB_C / 16];
+        CB_RD8(fr, fa, 0);
+        CB_RD8(fr, fa, 8);
+        // TWO accumulator chains (even / odd channel groups), added at the end: a single chain of 16 dependent MFMAs runs at
+        // the instruction's result latency, not its issue rate — PMC of the one-chain form: 1360 of 2880 cycles per tile in
+        // issue stalls, matrix pipes 22 % busy.  (The sum order only has to be the same in both passes: it is, same code.)
+        f32x16 acc, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
+        CB_WAIT8(fr, 0, 8);
+#pragma unroll
+        for (int s = 0; s < 8; s += 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&fr[s]), qf[s], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&fr[s + 1]), qf[s + 1], acc1, 0, 0, 0);
+        }
+        CB_WAIT8(fr, 8, 0);
+#pragma unroll
+        for (int s = 8; s < 16; s += 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&fr[s]), qf[s], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&fr[s + 1]), qf[s + 1], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+        CB_STAMP();
         const int k0 = t * CB_KT;
         if (k0 + CB_KT > P) {          // partial last tile only (wave-uniform): keys beyond P never win
 #pragma unroll
@@ -201,26 +306,35 @@ __global__ __launch_bounds__(256, 2) void corr_bf16_kernel(CorrBf16Args a) {
             for (int r = 0; r < 16; ++r) {
                 if (acc[r] >= thr) {
                     const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const int pos = atomicAdd(a.cnt + (long)b * P + query, 1);
-                    if (pos < CB_CAP) a.list[((long)b * P + query) * CB_CAP + pos] = key;
+                    if (cn >= 4) {      // a fifth candidate in one lane (clustered exemplar features): appended at once
+                        const int pos = atomicAdd(a.cnt + (long)b * P + query, 1);
+                        if (pos < CB_CAP) a.list[((long)b * P + query) * CB_CAP + pos] = key;
+                    }
+                    ck0 = cn == 0 ? key : ck0;
+                    ck1 = cn == 1 ? key : ck1;
+                    ck2 = cn == 2 ? key : ck2;
+                    ck3 = cn == 3 ? key : ck3;
+                    ++cn;
                 }
             }
         }
-        __syncthreads();
     }
-    if (PASS == 1 && qvalid) a.part_max[((long)b * a.nslot + split * 2 + hi) * P + query] = lmax;
-}
-
-// row maximum over the partial maxima of pass 1; also clears the candidate counter pass 2 appends to
-__global__ __launch_bounds__(256) void corr_bf16_max_kernel(const float* __restrict__ part, int nslot, int P,
-                                                            float* __restrict__ row_max, int* __restrict__ cnt) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (q >= P) return;
-    float m = -INFINITY;
-    for (int s = 0; s < nslot; ++s) m = fmaxf(m, part[((long)b * nslot + s) * P + q]);
-    row_max[(long)b * P + q] = m;
-    cnt[(long)b * P + q] = 0;
+    CB_STAMP();
+    if (kDvcDebug && dbgp) dbgp[255] = dbgi;
+    if (PASS == 2 && cn > 0) {
+        int* cq = a.cnt + (long)b * P + query;
+        const int nk = cn < 4 ? cn : 4;        // (candidates beyond the fourth were appended inside the loop)
+        const int pos = atomicAdd(cq, nk);
+        int* lq = a.list + ((long)b * P + query) * CB_CAP;
+        if (pos + 0 < CB_CAP) lq[pos + 0] = ck0;
+        if (nk > 1 && pos + 1 < CB_CAP) lq[pos + 1] = ck1;
+        if (nk > 2 && pos + 2 < CB_CAP) lq[pos + 2] = ck2;
+        if (nk > 3 && pos + 3 < CB_CAP) lq[pos + 3] = ck3;
+    }
+    if (PASS == 1 && qvalid) {
+        a.part_max[((long)b * P + query) * a.nslot + split * 2 + hi] = lmax;
+        if (split == 0 && hi == 0) a.cnt[(long)b * P + query] = 0;      // the counter pass 2 appends to
+    }
 }
 
 // one wave per query: exact fp32 re-scoring of the candidates + max / softmax / colour gather
@@ -355,7 +469,7 @@ __global__ __launch_bounds__(256) void corr_bf16_rescore_kernel(const float* __r
 static void corr_bf16_split(int B, int P, int* ntiles, int* tps, int* nsplit) {
     int qblocks = cdiv(P, CB_QB);
     *ntiles = cdiv(P, CB_KT);
-    int want = 512 / (qblocks * B);
+    int want = 256 / (qblocks * B);      // one 8-wave workgroup per CU
     if (want < 1) want = 1;
     if (want > *ntiles) want = *ntiles;
     *tps = cdiv(*ntiles, want);
@@ -389,22 +503,23 @@ extern "C" int dvc_corr_fwd_bf16(const void* theta_bf16_pc, const void* phi_bf16
     a.theta = reinterpret_cast<const unsigned short*>(theta_bf16_pc);
     a.phi = reinterpret_cast<const unsigned short*>(phi_bf16_pc);
     a.P = P;
+    a.dbg = nullptr;
+#ifdef DVC_DEBUG
+    extern long long* g_corr_bf16_dbg;
+    a.dbg = g_corr_bf16_dbg;
+#endif
     int nsplit;
     corr_bf16_split(B, P, &a.ntiles, &a.tiles_per_split, &nsplit);
     a.nslot = nsplit * 2;
     const size_t n = (size_t)B * P;
     a.part_max = reinterpret_cast<float*>(workspace);
-    float* row_max = a.part_max + n * a.nslot;
-    a.row_max = row_max;
-    a.cnt = reinterpret_cast<int*>(row_max + n);
+    a.cnt = reinterpret_cast<int*>(a.part_max + n * a.nslot + n);     // (one unused [B][P] float slot kept: workspace layout of ABI v9)
     a.list = a.cnt + n;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(cdiv(P, CB_QB), nsplit, B);
-    hipLaunchKernelGGL(corr_bf16_kernel<1>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(corr_bf16_kernel<1>, grid, dim3(512), 0, s, a);
     DVC_CHECK_LAUNCH("dvc_corr_fwd_bf16(pass1)");
-    hipLaunchKernelGGL(corr_bf16_max_kernel, dim3(cdiv(P, 256), B), dim3(256), 0, s, a.part_max, a.nslot, P, row_max, a.cnt);
-    DVC_CHECK_LAUNCH("dvc_corr_fwd_bf16(max)");
-    hipLaunchKernelGGL(corr_bf16_kernel<2>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(corr_bf16_kernel<2>, grid, dim3(512), 0, s, a);      // (takes the row maxima from pass 1's partial maxima itself)
     DVC_CHECK_LAUNCH("dvc_corr_fwd_bf16(pass2)");
     hipLaunchKernelGGL(corr_bf16_rescore_kernel, dim3(cdiv(P, 4), B), dim3(256), 0, s, theta_f32_pc, phi_f32_pc, blab,
                        a.cnt, a.list, temperature, P, h, w, y_small, sim_small, y_up, sim_up, argmax);
