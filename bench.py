@@ -288,9 +288,25 @@ def main():
     nets[1].corr_precision = args.corr
     use_graph = not args.no_graph and not args.no_exemplar_cache and args.front_batch == 1
     cc = ClipColorizer(*nets, temperature=1e-10, cache_exemplar=not args.no_exemplar_cache, graph=use_graph)
+    graph_note = None
     # exemplar: prepared on rank 0, shared once with every rank (RCCL broadcast over xGMI)
     IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).to(device)
     broadcast_exemplar(cc, IB if rank == 0 else None, (1, 3, H, W), device, src=0)
+
+    if use_graph:
+        # stream capture is exercised here, before anything is timed: if the runtime refuses it on this box the line is still
+        # produced — with every launch issued from Python, and saying so — instead of no line at all (results are identical)
+        try:
+            probe = synth.synth_lab(synth.FRAME_SEED0, H, W).to(device)
+            cc.frame(probe, torch.zeros_like(probe))
+            cc.clip([probe, probe, probe], lookahead=max(args.lookahead, 1))
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001
+            graph_note = f"hipGraph capture failed ({type(e).__name__}: {e}); fell back to launches from Python"
+            log("[bench]", graph_note)
+            use_graph = False
+            cc.graph = False            # (same driver, same exemplar state: no collective on this path)
+            cc._graphs.clear()
 
     K, Wm = args.steps, args.warmup
     # this rank's contiguous chunk of the clip: warm-up frames then K timed frames (resident in HBM)
@@ -447,7 +463,7 @@ def main():
                        "ColorVidNet recurrence on the main stream (bit-identical to per-frame calls)",
                        "launches": "captured per-frame launch sequences replayed as hipGraphs (front end per side stream, "
                                    "ColorVidNet chain), bit-identical to eager launches" if use_graph else
-                                   "every kernel launched from Python",
+                                   (graph_note or "every kernel launched from Python"),
                        "per_frame_api_frames_per_s": None if seq_fps is None else round(seq_fps, 3),
                        "eager_launch_clip_driver_frames_per_s": None if eager_fps is None else round(eager_fps, 3)},
             "roofline": roof,
