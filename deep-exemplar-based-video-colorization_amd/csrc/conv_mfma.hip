@@ -383,7 +383,9 @@ extern "C" int dvc_winograd_pack_weight(const float* w, int32_t Cout, int32_t Ci
 }
 
 // workgroup shapes (cfg / 4): channels = 32 wm, tile blocks = wn, input channels per LDS chunk = kc, workgroups resident per CU
-static const struct { int wm, wn, kc, per_cu; } kWinoShapes[3] = {{4, 1, 4, 1}, {2, 2, 8, 1}, {2, 1, 4, 2}};
+// (shape 3, one wave pair per workgroup, is reachable through cfg 12..15 only: tools/conv_wino_ab.py, measured in
+// profiles/r03_conv_wino_small_wg.txt; the cost model below keeps choosing among the first three)
+static const struct { int wm, wn, kc, per_cu; } kWinoShapes[4] = {{4, 1, 4, 1}, {2, 2, 8, 1}, {2, 1, 4, 2}, {1, 1, 4, 4}};
 
 // The plan of a Winograd launch: workgroup shape m, tile-block shape TR x (32/TR), split S over input-channel chunks.
 // Cost in MFMA-times per SIMD: rounds of workgroups x (chunks x MFMAs per chunk + a per-workgroup prologue/epilogue) + a
@@ -397,10 +399,11 @@ static void wino_plan(const DvcConvDesc* d, int OH, int OW, bool have_workspace,
     int best_m = -1, best_tr = 1, best_S = 1;
     double best_cost = 1e30;
     const int shape_cfg = d->cfg >= 0 ? d->cfg : -1;
-    for (int m = 0; m < 3; ++m) {
+    for (int m = 0; m < 4; ++m) {
         const int wm = kWinoShapes[m].wm, wn = kWinoShapes[m].wn, kc = kWinoShapes[m].kc;
         if (d->Cout % (32 * wm) != 0) continue;
         if (shape_cfg >= 0 && shape_cfg / 4 != m) continue;
+        if (shape_cfg < 0 && m == 3) continue;
         const int nch = d->Cin / kc;
         for (int ti = 0; ti < 4; ++ti) {
             const int tr = kTR[ti];
@@ -550,7 +553,8 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
         dim3 grid((unsigned)(s.gx * s.gy * s.gz));      // 1-D: the kernel maps it XCD-aware onto (gx, gy, gz)
         if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
         else if (best_m == 1) conv_wino_launch_m2(best_tr, grid, st, s);
-        else conv_wino_launch_m1(best_tr, grid, st, s);
+        else if (best_m == 2) conv_wino_launch_m1(best_tr, grid, st, s);
+        else conv_wino_launch_m0(best_tr, grid, st, s);
         DVC_CHECK_LAUNCH("dvc_conv2d_winograd");
         if (a.split > 1 && !(d->flags & DVC_CONV_DEFER_REDUCE)) {
             const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)NB * per_img) % 4 == 0);

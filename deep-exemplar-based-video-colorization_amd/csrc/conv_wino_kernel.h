@@ -475,3 +475,4 @@ static void conv_wino_launch_shape(int tr, dim3 grid, hipStream_t st, const Conv
 void conv_wino_launch_m4(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s);   // 128 channels x 32 tiles, 8 waves
 void conv_wino_launch_m2(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s);   // 64 channels x 64 tiles, 8 waves
 void conv_wino_launch_m1(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s);   // 64 channels x 32 tiles, 4 waves, two per CU
+void conv_wino_launch_m0(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s);   // 32 channels x 32 tiles, 2 waves, four per CU

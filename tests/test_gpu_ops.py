@@ -240,7 +240,7 @@ def test_winograd_pack_weight(ops):
 
 @pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
 @pytest.mark.parametrize("cfg,split_k", [(-1, 0), (0, 1), (1, 2), (2, 1), (3, 3), (4, 1), (5, 2), (6, 0), (7, 1),
-                                         (8, 1), (9, 2), (10, 0), (11, 3)])
+                                         (8, 1), (9, 2), (10, 0), (11, 3), (12, 1), (13, 0), (14, 2), (15, 1)])
 def test_conv2d_winograd(ops, case, cfg, split_k):
     """Winograd F(2x2,3x3) path (every tile-block shape x both workgroup shapes, with and without the split over input
     channels): the fp64 reference at a tolerance ~2.5x the direct engine's (the transform's known rounding),

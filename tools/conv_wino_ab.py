@@ -37,6 +37,8 @@ def timeit(fn, n=20):
 
 
 tot = {v: 0.0 for v in VARIANTS}
+CFGS = [tuple(int(t) for t in p.split(":")) for p in os.environ.get("WINO_CFGS", "").split(",") if p]
+tot_forced = [0.0]
 for (cnt, ci, co, H, W, dil, up) in LAYERS:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, ci, H, W, generator=g).to(dev)
@@ -57,8 +59,25 @@ for (cnt, ci, co, H, W, dil, up) in LAYERS:
     lib.dvc_debug_conv_variant(0)
     same = all(torch.equal(outs[v], outs[VARIANTS[0]]) for v in VARIANTS)
     gf = 2.0 * ci * co * 9 * (H * up) * (W * up) / 1e9
-    print(f"x{cnt:<2d} {ci:4d}->{co:4d} {H:3d}x{W:3d} d{dil} up{up} {gf:6.2f} GF: " +
-          "  ".join(f"v{v}: {best[v]:6.1f} us" for v in VARIANTS) + f"  identical: {same}", flush=True)
+    line = (f"x{cnt:<2d} {ci:4d}->{co:4d} {H:3d}x{W:3d} d{dil} up{up} {gf:6.2f} GF: " +
+            "  ".join(f"v{v}: {best[v]:6.1f} us" for v in VARIANTS) + f"  identical: {same}")
+    # forced workgroup shapes / splits (WINO_CFGS="cfg:split,..."; cfg = 4 * shape + tile-block index): best of them per layer
+    if CFGS:
+        cb = {}
+        for (cfg, sk) in CFGS:
+            try:
+                f = lambda: ops.conv2d_winograd(x, u, b, dil=dil, in_up=up, act=ops.ACT_RELU, cfg=cfg, split_k=sk)   # noqa: E731
+                ref = f()
+                assert (ref - outs[VARIANTS[0]]).abs().max().item() <= 2e-5 * outs[VARIANTS[0]].abs().max().item() + 1e-6
+                cb[(cfg, sk)] = min(timeit(f) for _ in range(3))
+            except RuntimeError:
+                pass
+        if cb:
+            k = min(cb, key=cb.get)
+            line += f"  | forced best cfg {k[0]} split {k[1]}: {cb[k]:6.1f} us"
+            tot_forced[0] += cnt * min(cb[k], best[VARIANTS[0]])
+    print(line, flush=True)
     for v in VARIANTS:
         tot[v] += cnt * best[v]
-print("per frame (these layers): " + "  ".join(f"v{v}: {tot[v] / 1e3:.3f} ms" for v in VARIANTS))
+print("per frame (these layers): " + "  ".join(f"v{v}: {tot[v] / 1e3:.3f} ms" for v in VARIANTS) +
+      (f"  | with the forced shapes where they win: {tot_forced[0] / 1e3:.3f} ms" if CFGS else ""))
