@@ -614,6 +614,21 @@ def test_graph_replay_equals_eager():
     ref3 = eager.clip(frames, lookahead=0)
     got3 = cc.clip(frames, lookahead=2)
     assert all(torch.equal(a, b) for a, b in zip(got3, ref3)) and not torch.equal(ref3[0], ref2[0])
+    # the bf16 candidate-filter correlation (configs[4]) inside the captured front end: atomics, counters and all
+    nets[1].corr_precision = "bf16"
+    try:
+        e16 = ClipColorizer(*nets, temperature=1e-10)
+        e16.set_exemplar(IB)
+        g16 = ClipColorizer(*nets, temperature=1e-10, graph=True)
+        g16.set_exemplar(IB)
+        ref16 = e16.clip(frames, lookahead=0)
+        for la in (0, 2):
+            got16 = g16.clip(frames, lookahead=la)
+            assert all(torch.equal(a, b) for a, b in zip(got16, ref16)), la
+        got16 = g16.clip(frames, lookahead=2)          # replayed again: the candidate counters are reset inside the sequence
+        assert all(torch.equal(a, b) for a, b in zip(got16, ref16))
+    finally:
+        nets[1].corr_precision = "fp32"
     # a graph-mode driver without an exemplar cache says so
     with pytest.raises(RuntimeError, match="exemplar cache"):
         bad = ClipColorizer(*nets, temperature=1e-10, cache_exemplar=False, graph=True)
