@@ -428,6 +428,17 @@ static void wino_plan(const DvcConvDesc* d, int OH, int OW, bool have_workspace,
             }
         }
     }
+#ifdef DVC_DEBUG
+    // dvc_debug_conv_variant(64): twice the split (shorter-lived workgroups) — tools/bg_split_probe.py asks whether front-end
+    // launches that run as background work delay the high-priority chain less that way
+    if ((g_conv_dbg & 64) && d->split_k == 0 && have_workspace && best_m >= 0) {
+        const int kc = kWinoShapes[best_m].kc, nch = d->Cin / kc;
+        int S2 = best_S * 2;
+        while (S2 > best_S && (S2 > 8 || S2 > nch / 2 || (size_t)S2 * d->Cout * OH * OW * sizeof(float) > workspace_bytes ||
+                               cdiv(nch, cdiv(nch, S2)) != S2)) --S2;
+        best_S = S2;
+    }
+#endif
     *best_m_out = best_m; *best_tr_out = best_tr; *best_S_out = best_S;
 }
 
