@@ -183,11 +183,15 @@ class ClipColorizer:
 
     # ---- captured launch sequences ------------------------------------------------------------------------------
     def _captured(self, kind, shape, device, slot, stream):
-        key = (kind, tuple(shape), slot)
+        # (everything a captured launch bakes in besides addresses: the frame geometry, the temperature — a kernel argument and
+        # the choice of the correlation's instantiation — and the correlation precision)
+        key = (kind, tuple(shape), slot, float(self.temperature), getattr(self.warp, "corr_precision", "fp32"))
         g = self._graphs.get(key)
         if g is None or g.seq.stale():
             if self.ex_cache is None:
                 raise RuntimeError("ClipColorizer(graph=True) needs the exemplar cache (cache_exemplar=True + set_exemplar)")
+            if g is not None:
+                torch.cuda.synchronize()        # a replay of the sequence being replaced may still be in flight
             self.prepare()
             g = (_FrontSlot if kind == "front" else _ColorChain)(self, shape, device, stream)
             self._graphs[key] = g
