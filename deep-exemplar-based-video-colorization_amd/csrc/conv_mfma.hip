@@ -438,6 +438,14 @@ static void wino_plan(const DvcConvDesc* d, int OH, int OW, bool have_workspace,
                                cdiv(nch, cdiv(nch, S2)) != S2)) --S2;
         best_S = S2;
     }
+    // dvc_debug_conv_variant(128 / 256): half the split / no split (fewer partial sums, longer workgroups, chip under-filled by
+    // this launch alone) — the same probe asks whether the multi-stream driver prefers that
+    if ((g_conv_dbg & (128 | 256)) && d->split_k == 0 && best_m >= 0 && best_S > 1) {
+        const int kc = kWinoShapes[best_m].kc, nch = d->Cin / kc;
+        int S2 = (g_conv_dbg & 256) ? 1 : best_S / 2;
+        while (S2 > 1 && cdiv(nch, cdiv(nch, S2)) != S2) --S2;
+        best_S = S2 < 1 ? 1 : S2;
+    }
 #endif
     *best_m_out = best_m; *best_tr_out = best_tr; *best_S_out = best_S;
 }

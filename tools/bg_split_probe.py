@@ -38,8 +38,25 @@ def warp_color_bg(*a, **k):
 
 
 frame.warp_color = warp_color_bg
-for name, v in (("front ends with the library's plan", 0), ("front ends with twice the split", 64), ("library's plan again", 0)):
+real_col_forward = type(nets[2]).forward
+cmode = {"v": 0}
+
+
+def col_forward(self, x):
+    lib.dvc_debug_conv_variant(cmode["v"])
+    try:
+        return real_col_forward(self, x)
+    finally:
+        lib.dvc_debug_conv_variant(0)
+
+
+type(nets[2]).forward = col_forward
+for name, v, cv in (("library's plan everywhere", 0, 0), ("front ends with twice the split", 64, 0), ("front ends with half the split", 128, 0),
+                    ("front ends without split", 256, 0), ("ColorVidNet chain with half the split", 0, 128),
+                    ("ColorVidNet chain without split", 0, 256), ("both with half the split", 128, 128), ("ColorVidNet chain with twice the split", 0, 64),
+                    ("chain twice, front ends half", 128, 64), ("library's plan again", 0, 0)):
     mode["v"] = v
+    cmode["v"] = cv
     cc.clip(fr[:6], lookahead=2)
     torch.cuda.synchronize()
     best = 1e9
