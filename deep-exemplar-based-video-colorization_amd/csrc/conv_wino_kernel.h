@@ -464,11 +464,14 @@ static void conv_wino_launch_shape(int tr, dim3 grid, hipStream_t st, const Conv
         return;
     }
 #endif
+    // (dvc_debug_conv_variant(512), debug build: pad the launch with dynamic LDS so that only ONE such workgroup fits a CU next
+    // to a 61 KB one — tools/bg_split_probe.py asks whether background launches that leave a slot per CU free help the chain)
+    const unsigned dyn = (kDvcDebug && (s.k.dbg & 512)) ? 36u * 1024u : 0u;
     switch (tr) {
-        case 1: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 1, KC>), grid, dim3(NT), 0, st, s); break;
-        case 2: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 2, KC>), grid, dim3(NT), 0, st, s); break;
-        case 4: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 4, KC>), grid, dim3(NT), 0, st, s); break;
-        default: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 8, KC>), grid, dim3(NT), 0, st, s); break;
+        case 1: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 1, KC>), grid, dim3(NT), dyn, st, s); break;
+        case 2: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 2, KC>), grid, dim3(NT), dyn, st, s); break;
+        case 4: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 4, KC>), grid, dim3(NT), dyn, st, s); break;
+        default: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 8, KC>), grid, dim3(NT), dyn, st, s); break;
     }
 }
 

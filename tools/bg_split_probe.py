@@ -51,7 +51,7 @@ def col_forward(self, x):
 
 
 type(nets[2]).forward = col_forward
-for name, v, cv in (("library's plan everywhere", 0, 0), ("front ends with twice the split", 64, 0), ("front ends with half the split", 128, 0),
+for name, v, cv in (("library's plan everywhere", 0, 0), ("front-end Winograd launches padded to one workgroup per CU", 512, 0), ("front ends with twice the split", 64, 0), ("front ends with half the split", 128, 0),
                     ("front ends without split", 256, 0), ("ColorVidNet chain with half the split", 0, 128),
                     ("ColorVidNet chain without split", 0, 256), ("both with half the split", 128, 128), ("ColorVidNet chain with twice the split", 0, 64),
                     ("chain twice, front ends half", 128, 64), ("library's plan again", 0, 0)):
