@@ -391,7 +391,7 @@ static const struct { int wm, wn, kc, per_cu; } kWinoShapes[4] = {{4, 1, 4, 1}, 
 // Cost in MFMA-times per SIMD: rounds of workgroups x (chunks x MFMAs per chunk + a per-workgroup prologue/epilogue) + a
 // reduce launch.  A pure function of the descriptor and the workspace size (dvc_conv2d_winograd_split exposes S).
 static void wino_plan(const DvcConvDesc* d, int OH, int OW, bool have_workspace, size_t workspace_bytes, int* best_m_out,
-                      int* best_tr_out, int* best_S_out) {
+                      int* best_tr_out, int* best_S_out, int force_m = -1) {
     const int ss = d->dil;
     const int TY = cdiv(cdiv(OH, ss), 2), TX = cdiv(cdiv(OW, ss), 2);
     const int ncu = conv_num_cus();
@@ -404,6 +404,7 @@ static void wino_plan(const DvcConvDesc* d, int OH, int OW, bool have_workspace,
         if (d->Cout % (32 * wm) != 0) continue;
         if (shape_cfg >= 0 && shape_cfg / 4 != m) continue;
         if (shape_cfg < 0 && m == 3) continue;
+        if (force_m >= 0 && m != force_m) continue;
         const int nch = d->Cin / kc;
         for (int ti = 0; ti < 4; ++ti) {
             const int tr = kTR[ti];
@@ -495,9 +496,11 @@ extern "C" int dvc_conv2d_winograd_split(const DvcConvDesc* d, size_t workspace_
     return 0;
 }
 
-extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const float* u_packed, const float* bias,
-                                   const float* act_slope_ptr, const float* residual, float* y, void* workspace,
-                                   size_t workspace_bytes, dvcStream stream) {
+// d2 / x2 != NULL: the two-input form (dvc_conv2d_winograd_dual) — `d` then carries the TOTAL channel count and the first
+// input's geometry, `d2` the second input's (Cin, H, W, in_up, in_sub).
+static int wino_run(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x, const float* x2, const float* u_packed,
+                    const float* bias, const float* act_slope_ptr, const float* residual, float* y, void* workspace,
+                    size_t workspace_bytes, dvcStream stream) {
     DVC_REQUIRE(d && x && u_packed && y, "dvc_conv2d_winograd: null argument");
     DVC_REQUIRE(d->ksize == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil,
                 "dvc_conv2d_winograd: needs a 3x3 stride-1 layer with pad == dilation (1 or 2)");
@@ -511,6 +514,7 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
     DVC_REQUIRE((long)d->Cin * d->H * d->W * 4 < (1L << 31) && (long)d->Cin * 2048 * 4 < (1L << 31),
                 "dvc_conv2d_winograd: tensor too large for buffer-descriptor staging");
     ConvWinoArgs s;
+    s.x2 = nullptr; s.x2_bs = 0; s.cinA = d->Cin; s.H2 = s.W2 = s.VH2 = s.VW2 = 0; s.in_up2 = s.in_sub2 = 1;
     ConvKArgs& a = s.k;
     a.x = x; a.w = u_packed; a.bias = bias; a.in_scale = nullptr; a.in_shift = nullptr;
     a.in_slope_ptr = nullptr; a.act_slope_ptr = act_slope_ptr; a.res = residual; a.y = y;
@@ -534,7 +538,21 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
     s.ss = d->dil;
     const int TY = cdiv(cdiv(OH, s.ss), 2), TX = cdiv(cdiv(OW, s.ss), 2);   // 2x2 tiles of one parity class
     int best_m = -1, best_tr = 1, best_S = 1;
-    wino_plan(d, OH, OW, workspace != nullptr, workspace_bytes, &best_m, &best_tr, &best_S);
+    if (d2) {
+        s.x2 = x2;
+        s.cinA = d->Cin - d2->Cin;
+        s.H2 = d2->H; s.W2 = d2->W;
+        s.VH2 = virt_dim(d2->H, d2->in_up, d2->in_sub);
+        s.VW2 = virt_dim(d2->W, d2->in_up, d2->in_sub);
+        s.in_up2 = d2->in_up; s.in_sub2 = d2->in_sub;
+        s.x2_bs = d2->x_batch_stride ? d2->x_batch_stride : (long)d2->Cin * d2->H * d2->W;
+        DVC_REQUIRE(s.VH2 == a.VH && s.VW2 == a.VW, "dvc_conv2d_winograd_dual: the two inputs' virtual sizes differ (%d x %d vs %d x %d)",
+                    a.VH, a.VW, s.VH2, s.VW2);
+        DVC_REQUIRE((long)d2->Cin * d2->H * d2->W * 4 < (1L << 31), "dvc_conv2d_winograd_dual: second input too large");
+        // the first input's rsrc covers only its own channels
+        a.x_bs = d->x_batch_stride ? d->x_batch_stride : (long)s.cinA * d->H * d->W;
+    }
+    wino_plan(d, OH, OW, workspace != nullptr, workspace_bytes, &best_m, &best_tr, &best_S, d2 ? 2 : -1);
     DVC_REQUIRE(best_m >= 0, "dvc_conv2d_winograd: no configuration for cfg %d / split_k %d on this layer", d->cfg, d->split_k);
     const int wm = kWinoShapes[best_m].wm, wn = kWinoShapes[best_m].wn, kc = kWinoShapes[best_m].kc;
     const int nch = d->Cin / kc;
@@ -560,6 +578,7 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
         const int NB = std::min(group, d->N - n0);
         a.N = NB;
         a.x = x + (long)n0 * a.x_bs;
+        if (d2) s.x2 = x2 + (long)n0 * s.x2_bs;
         a.y = y + (long)n0 * a.y_bs;
         a.res = residual ? residual + (long)n0 * a.res_bs : nullptr;
         s.gz = NB * a.split;
@@ -570,7 +589,8 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
         s.m_blkx = wino_magic(s.blk_x);
         s.m_split = wino_magic(a.split);
         dim3 grid((unsigned)(s.gx * s.gy * s.gz));      // 1-D: the kernel maps it XCD-aware onto (gx, gy, gz)
-        if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
+        if (d2) conv_wino_launch_m1_dual(best_tr, grid, st, s);
+        else if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
         else if (best_m == 1) conv_wino_launch_m2(best_tr, grid, st, s);
         else if (best_m == 2) conv_wino_launch_m1(best_tr, grid, st, s);
         else conv_wino_launch_m0(best_tr, grid, st, s);
@@ -589,6 +609,29 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
         }
     }
     return 0;
+}
+
+extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const float* u_packed, const float* bias,
+                                   const float* act_slope_ptr, const float* residual, float* y, void* workspace,
+                                   size_t workspace_bytes, dvcStream stream) {
+    return wino_run(d, nullptr, x, nullptr, u_packed, bias, act_slope_ptr, residual, y, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dvc_conv2d_winograd_dual(const DvcConvDesc* dA, const DvcConvDesc* dB, const float* xA, const float* xB,
+                                        const float* u_packed_cat, const float* bias, const float* act_slope_ptr, float* y,
+                                        void* workspace, size_t workspace_bytes, dvcStream stream) {
+    DVC_REQUIRE(dA && dB && xA && xB && u_packed_cat && y, "dvc_conv2d_winograd_dual: null argument");
+    DVC_REQUIRE(dA->N == dB->N && dA->Cout == dB->Cout && dA->dil == dB->dil && dA->pad_mode == dB->pad_mode && dB->ksize == 3 &&
+                    dB->stride == 1 && dB->pad == dB->dil,
+                "dvc_conv2d_winograd_dual: the two convolutions must agree in batch, output channels, dilation and padding");
+    DVC_REQUIRE(dA->Cin % 8 == 0 && dB->Cin % 8 == 0, "dvc_conv2d_winograd_dual: both channel counts must be multiples of 8");
+    DVC_REQUIRE((dB->in_up == 1 || dB->in_up == 2) && (dB->in_sub == 1 || dB->in_sub == 2) && !(dB->in_up == 2 && dB->in_sub == 2),
+                "dvc_conv2d_winograd_dual: bad in_up/in_sub of the second input");
+    DVC_REQUIRE(!(dA->flags & DVC_CONV_DEFER_REDUCE), "dvc_conv2d_winograd_dual: no deferred reduce on this entry");
+    DvcConvDesc d = *dA;
+    d.Cin = dA->Cin + dB->Cin;
+    d.x_batch_stride = dA->x_batch_stride ? dA->x_batch_stride : (int64_t)dA->Cin * dA->H * dA->W;
+    return wino_run(&d, dB, xA, xB, u_packed_cat, bias, act_slope_ptr, nullptr, y, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -57,6 +57,12 @@ struct ConvWinoArgs {
     // ceil(2^32 / d) for the divisors of the workgroup-index decode — exact quotients by one s_mul_hi for numerators and
     // divisors < 2^16, which the launcher guarantees (it caps the images per launch): gx, gx * gy, blk_y * blk_x, blk_x, split
     unsigned m_gx, m_gxy, m_cls, m_blkx, m_split;
+    // DUAL instantiations (dvc_conv2d_winograd_dual): the reduction runs over the channels of TWO inputs with their own
+    // index maps — the first cinA channels of the packed filters belong to k.x (geometry in k), the rest to x2 (geometry
+    // below); k.Cin is the total.  One launch for ColorVidNet's `conv8_1(up(n7)) + conv3_3_short(n3)` pairs.
+    const float* x2;
+    long x2_bs;
+    int cinA, H2, W2, VH2, VW2, in_up2, in_sub2;
 };
 __host__ __device__ __forceinline__ unsigned wino_magic(long d) {      // (d == 1: 2^32 does not fit; 0 means "quotient = n")
     return d > 1 ? (unsigned)(((1ULL << 32) + (unsigned long long)d - 1) / (unsigned long long)d) : 0u;
@@ -118,7 +124,21 @@ __host__ __device__ constexpr int wino_pitch(int tr) { return tr == 1 ? 66 : tr 
 #define WINO_S_ADD(D, A, B) asm volatile("v_add_f32 %0, %1, %2" : "=v"(D) : "v"(A), "v"(B))
 #define WINO_S_SUB(D, A, B) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(D) : "v"(A), "v"(B))
 
-template <int WM, int WN, int TR, int KC, int VAR = 0>
+__device__ __forceinline__ int wino_stored_offset(int VH, int VW, int W, int in_up, int in_sub, int pad_mode, int vy, int vx) {
+    int sy = map_virtual(vy, VH, pad_mode);
+    int sx = map_virtual(vx, VW, pad_mode);
+    if (sy < 0 || sx < 0) return -1;
+    if (in_up == 2) {
+        sy >>= 1;
+        sx >>= 1;
+    } else if (in_sub == 2) {
+        sy <<= 1;
+        sx <<= 1;
+    }
+    return sy * W + sx;
+}
+
+template <int WM, int WN, int TR, int KC, int VAR = 0, bool DUAL = false>
 __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_kernel(ConvWinoArgs s) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvKArgs& a = s.k;
@@ -208,14 +228,43 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
         }
         gofs[t] = g >= 0 ? g * 4 : OOB;
     }
+    const int cinA = DUAL ? s.cinA : a.Cin;        // channels that come from a.x
     __amdgpu_buffer_rsrc_t rs_x =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long)n * a.x_bs), 0, a.Cin * HWi * 4, 0x00020000);
-    auto issue_x = [&](int c, int buf) {
-        const int sx = c * KC * HWi * 4;
-        float* xs = xsb + buf * C_XS;
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long)n * a.x_bs), 0, cinA * HWi * 4, 0x00020000);
+    // second input (DUAL): its own patch plan (another stored size / upsampling), same LDS image
+    int gofs2[DUAL ? EPT : 1];
+    const int HWi2 = DUAL ? s.H2 * s.W2 : 0;
+    if (DUAL) {
 #pragma unroll
-        for (int t = 0; t < EPT; ++t)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (CONV_AS3 void*)(xs + t * NT + wave * 64), 4, gofs[t], sx, 0, 0);
+        for (int t = 0; t < EPT; ++t) {
+            const int e = tid + t * NT;
+            const int c = e / plane, rem = e - c * plane;
+            const int iy = rem / PITCH, ix = rem - iy * PITCH;
+            int g = -1;
+            if (e < KC * plane && ix < PC) {
+                const int o = wino_stored_offset(s.VH2, s.VW2, s.W2, s.in_up2, s.in_sub2, a.pad_mode, ss * (2 * ty0 - 1 + iy) + py,
+                                                 ss * (2 * tx0 - 1 + ix) + px);
+                if (o >= 0) g = c * HWi2 + o;
+            }
+            gofs2[DUAL ? t : 0] = g >= 0 ? g * 4 : OOB;
+        }
+    }
+    __amdgpu_buffer_rsrc_t rs_x2 = rs_x;
+    if (DUAL)
+        rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(s.x2 + (long)n * s.x2_bs), 0, (a.Cin - cinA) * HWi2 * 4, 0x00020000);
+    const int nchA = cinA / KC;
+    auto issue_x = [&](int c, int buf) {
+        float* xs = xsb + buf * C_XS;
+        // (DUAL: descriptor, scalar offset and lane offsets SELECTED, not branched on — the K loop stays one basic block, which
+        // is what its hand-placed interleaving of DMA issue and MFMAs relies on)
+        const bool first = !DUAL || c < nchA;
+        const __amdgpu_buffer_rsrc_t rs = first ? rs_x : rs_x2;
+        const int sx = first ? c * KC * HWi * 4 : (c - nchA) * KC * HWi2 * 4;
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            const int go = first ? gofs[t] : gofs2[DUAL ? t : 0];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (CONV_AS3 void*)(xs + t * NT + wave * 64), 4, go, sx, 0, 0);
+        }
     };
     auto issue = [&](int c, int buf) {
         issue_x(c, buf);
@@ -475,6 +524,18 @@ static void conv_wino_launch_shape(int tr, dim3 grid, hipStream_t st, const Conv
     }
 }
 
+template <int WM, int WN, int KC>
+static void conv_wino_launch_shape_dual(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s) {
+    constexpr int NT = 128 * WM * WN;
+    switch (tr) {
+        case 1: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 1, KC, 0, true>), grid, dim3(NT), 0, st, s); break;
+        case 2: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 2, KC, 0, true>), grid, dim3(NT), 0, st, s); break;
+        case 4: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 4, KC, 0, true>), grid, dim3(NT), 0, st, s); break;
+        default: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 8, KC, 0, true>), grid, dim3(NT), 0, st, s); break;
+    }
+}
+
+void conv_wino_launch_m1_dual(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s);   // the two-input form, 64 x 32 shape only
 void conv_wino_launch_m4(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s);   // 128 channels x 32 tiles, 8 waves
 void conv_wino_launch_m2(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s);   // 64 channels x 64 tiles, 8 waves
 void conv_wino_launch_m1(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s);   // 64 channels x 32 tiles, 4 waves, two per CU

@@ -6,3 +6,7 @@
 void conv_wino_launch_m1(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s) {
     conv_wino_launch_shape<2, 1, 4>(tr, grid, st, s);
 }
+
+void conv_wino_launch_m1_dual(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s) {
+    conv_wino_launch_shape_dual<2, 1, 4>(tr, grid, st, s);
+}

@@ -43,6 +43,8 @@ SIGNATURES = {
                                                 ctypes.POINTER(c_i32)]),
     "dvc_conv2d_winograd": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                            ctypes.c_size_t, _VP]),
+    "dvc_conv2d_winograd_dual": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP,
+                                                _VP, _VP, ctypes.c_size_t, _VP]),
     "dvc_conv1x1_small": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, _VP, _VP]),
     "dvc_instnorm_stats": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, c_i64, ctypes.c_float, _VP, _VP, _VP, _VP]),
     "dvc_affine_act": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,

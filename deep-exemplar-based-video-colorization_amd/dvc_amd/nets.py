@@ -37,7 +37,11 @@ class _PackCache:
         self._d = {}
 
     def get(self, key, param, fn):
-        tag = (param.data_ptr(), param._version, str(param.device))
+        """`param`: a parameter, or a tuple of parameters (fn then receives the tuple) — e.g. the concatenated filters of two
+        convolutions that run as one launch."""
+        params = param if isinstance(param, tuple) else (param,)
+        tag = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        param = params[0]
         hit = self._d.get(key)
         if hit is None or hit[0] != tag:
             # Cold path (first use, or after load_state_dict / .cuda()).  The packed tensor is produced
@@ -50,7 +54,7 @@ class _PackCache:
             global _pack_epoch
             _pack_epoch += 1
             with torch.no_grad():
-                hit = (tag, fn(param))
+                hit = (tag, fn(params if len(params) > 1 else param))
             if param.is_cuda:
                 torch.cuda.synchronize(param.device)
             self._d[key] = hit
@@ -388,6 +392,41 @@ class ColorVidNet(nn.Module):
         out = self._mod(arch.CVN_OUT["key"])
         return self._cache.get("conv10_ab", out.weight, lambda w: w.detach().reshape(w.shape[0], -1).contiguous())
 
+    # ---- decoder blocks: `conv8_1(up(norm(c7_3))) + conv3_3_short(norm(c3_3))` (ColorVidNet.py:124-127; likewise conv9_1,
+    # conv10_1) as ONE launch over the channels of both inputs (ops.conv2d_winograd_dual) when both are Winograd layers
+    def _dual_pairs(self):
+        """consumer key -> the skip-convolution entry whose output it adds (a linear convolution read by nothing else)."""
+        by_dst = {c["dst"]: c for c in arch.CVN_CONVS}
+        uses = {}
+        for c in arch.CVN_CONVS:
+            uses[c["src"]] = uses.get(c["src"], 0) + 1
+            if c["add"] is not None:
+                uses[c["add"]] = uses.get(c["add"], 0) + 1
+        pairs = {}
+        for c in arch.CVN_CONVS:
+            e = by_dst.get(c["add"]) if c["add"] is not None else None
+            if e is not None and e["act"] == "none" and e["add"] is None and uses.get(e["dst"], 0) == 1 and e["dil"] == c["dil"] \
+                    and e["pre"] in (None, "norm") and c["pre"] in ("up", "norm", None):
+                pairs[c["key"]] = e
+        return pairs
+
+    def _dual_pack(self, cA, cB):
+        """(concatenated Winograd filters, summed bias) of a fused pair; cached per parameter versions like every pack."""
+        mA, mB = self._mod(cA["key"]), self._mod(cB["key"])
+        u = self._cache.get(cA["key"] + ":dual", (mA.weight, mB.weight), lambda ws: torch.cat(
+            (ops.pack_winograd_weight(ws[0]), ops.pack_winograd_weight(ws[1])), dim=1).contiguous())
+        b = self._cache.get(cA["key"] + ":dualbias", (mA.bias, mB.bias), lambda bs: (bs[0].detach() + bs[1].detach()).contiguous())
+        return u, b
+
+    def _dual_ok(self, cA, cB, shapeA, shapeB):
+        """Both convolutions of the pair go to the Winograd kernel under the current algorithm choice."""
+        if not ops.dual_conv_enabled():
+            return False
+        (N, CA, HA, WA), (_, CB, HB, WB) = shapeA, shapeB
+        upA = 2 if cA["pre"] == "up" else 1
+        return (ops.winograd_selected(N, CA, HA, WA, cA["cout"], dil=cA["dil"], pad=cA["dil"], in_up=upA)
+                and ops.winograd_selected(N, CB, HB, WB, cB["cout"], dil=cB["dil"], pad=cB["dil"]))
+
     def prepare(self):
         """Pack every weight now, on the current stream (see _PackCache.get)."""
         for c in arch.CVN_CONVS:
@@ -395,6 +434,10 @@ class ColorVidNet(nn.Module):
             if c["pre"] == "norm_ss":
                 self._ss_weight(c["ss"])
         self._out_weight()
+        if ops.conv_algo() != "direct" and ops.dual_conv_enabled():
+            by_key = {c["key"]: c for c in arch.CVN_CONVS}
+            for key, e in self._dual_pairs().items():
+                self._dual_pack(by_key[key], e)
 
     def forward(self, x):
         """ x: gray image (1 channel), ab(2 channel), ab_err, ba_err"""
@@ -436,7 +479,27 @@ class ColorVidNet(nn.Module):
         raw_use.add(arch.CVN_OUT.get("src", "c10_2"))
 
         act_map = {"relu": ops.ACT_RELU, "none": ops.ACT_NONE, "leaky": ops.ACT_LEAKY}
+        pairs = self._dual_pairs()
+        deferred = {e["key"] for e in pairs.values()}
         for c in arch.CVN_CONVS:
+            if c["key"] in deferred:
+                continue            # the skip convolution of a decoder block: runs with its consumer below (or just before it)
+            e = pairs.get(c["key"])
+            if e is not None:
+                srcA = norm_of(c["src"]) if c["pre"] in ("norm", "up") else acts[c["src"]]
+                srcB = norm_of(e["src"]) if e["pre"] == "norm" else acts[e["src"]]
+                if self._dual_ok(c, e, srcA.shape, srcB.shape):
+                    u, b = self._dual_pack(c, e)
+                    acts[c["dst"]] = ops.conv2d_winograd_dual(srcA, srcB, u, b, dil=c["dil"], in_upA=2 if c["pre"] == "up" else 1,
+                                                              act=act_map[c["act"]], act_slope=0.2)
+                    if c["dst"] in norm_uses:
+                        for ss_key in dict.fromkeys(norm_uses[c["dst"]]):
+                            norm_of(c["dst"], ss_key)
+                    continue
+                # not both Winograd layers (direct algorithm, tiny maps): the skip convolution as its own launch, then the adder
+                convE = self._mod(e["key"])
+                acts[e["dst"]] = ops.conv3x3(srcB, convE.weight, _packs(self._cache, e["key"], convE.weight), convE.bias.detach(),
+                                             dil=e["dil"], act=act_map[e["act"]], act_slope=0.2)
             conv = self._mod(c["key"])
             kw = dict(dil=c["dil"], act=act_map[c["act"]], act_slope=0.2)
             pre = c["pre"]

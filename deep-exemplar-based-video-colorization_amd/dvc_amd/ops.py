@@ -269,6 +269,48 @@ def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_
     return out
 
 
+def conv2d_winograd_dual(xA, xB, u_cat, bias, *, dil=1, pad_mode=PAD_ZERO, in_upA=1, in_upB=1, act=ACT_NONE, act_slope=0.0,
+                         act_slope_t=None):
+    """dvc_conv2d_winograd_dual: act(conv3x3(up_A(xA), W_A) + conv3x3(up_B(xB), W_B) + bias) in one launch.  u_cat = the two
+    packed filter sets concatenated along Cin (torch.cat((pack(W_A), pack(W_B)), dim=1)), bias = b_A + b_B."""
+    lib = _lib.load()
+    for t, nm in ((xA, "xA"), (xB, "xB"), (u_cat, "u_cat"), (bias, "bias"), (act_slope_t, "act_slope")):
+        _need(t, nm)
+    N, CA, HA, WA = xA.shape
+    NB, CB, HB, WB = xB.shape
+    assert N == NB and u_cat.dim() == 5 and u_cat.shape[1] == CA + CB and tuple(u_cat.shape[2:]) == (4, 32, 4), (xA.shape, xB.shape, u_cat.shape)
+    Cout = u_cat.shape[0] * 32
+    OH, OW = conv_out_hw(HA, WA, 3, 1, dil, dil, in_upA, 1)
+    if (OH, OW) != conv_out_hw(HB, WB, 3, 1, dil, dil, in_upB, 1):
+        raise RuntimeError(f"dvc_amd: conv2d_winograd_dual: the two inputs' virtual sizes differ ({HA * in_upA} x {WA * in_upA} vs "
+                           f"{HB * in_upB} x {WB * in_upB})")
+    dA = DvcConvDesc(N, CA, HA, WA, Cout, 3, 1, dil, dil, pad_mode, in_upA, 1, act, float(act_slope), 0, -1, 0, 0, 0, 0, 0)
+    dB = DvcConvDesc(N, CB, HB, WB, Cout, 3, 1, dil, dil, pad_mode, in_upB, 1, act, float(act_slope), 0, -1, 0, 0, 0, 0, 0)
+    if conv_record is not None:
+        conv_record.append(dict(N=N, Cin=CA + CB, H=OH, W=OW, Cout=Cout, ksize=3, stride=1, dil=dil, pad=dil, pad_mode=pad_mode,
+                                in_up=1, in_sub=1, affine=False, in_prelu=False, residual=False, act=act, algo="winograd-dual"))
+    ws = _workspace(xA.device, CONV_WORKSPACE_BYTES, "conv")
+    _bump_generation(ws)
+    out = torch.empty((N, Cout, OH, OW), device=xA.device, dtype=torch.float32)
+    _lib.check(lib.dvc_conv2d_winograd_dual(ctypes.byref(dA), ctypes.byref(dB), _p(xA), _p(xB), _p(u_cat), _p(bias), _p(act_slope_t),
+                                            _p(out), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+               "dvc_conv2d_winograd_dual")
+    return out
+
+
+# decoder-block pairs `conv(up(a)) + conv_short(b)` as one launch (DVC_DUAL_CONV=0 / set_dual_conv(False): two launches)
+_dual_conv = _os.environ.get("DVC_DUAL_CONV", "1") == "1"
+
+
+def set_dual_conv(flag=True):
+    global _dual_conv
+    _dual_conv = bool(flag)
+
+
+def dual_conv_enabled():
+    return _dual_conv
+
+
 # ---- algorithm choice for the 3x3 stride-1 layers.  "direct": the implicit-GEMM engine everywhere; "winograd": the
 # F(2x2,3x3) kernel on every layer it takes; "auto" (default): the static rule below, fitted to
 # profiles/r02_conv_wino_probe.txt (Winograd where it is measured faster).  The choice is a pure function of the layer

@@ -131,6 +131,18 @@ int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const float* u_pac
                         const float* bias /* may be NULL */, const float* act_slope_ptr /* device scalar or NULL */,
                         const float* residual /* or NULL */, float* y,
                         void* workspace /* or NULL */, size_t workspace_bytes, dvcStream stream);
+/* TWO 3x3 convolutions whose outputs are added, as ONE launch: y = act(conv(T_A(xA), W_A) + conv(T_B(xB), W_B) + bias).
+ * ColorVidNet.py:124-139 adds a skip convolution to the first convolution of every decoder block
+ * (conv8_1(up(norm(c7_3))) + conv3_3_short(norm(c3_3)), likewise conv9_1 / conv10_1): the reduction simply runs over the
+ * channels of both inputs, each with its own index map (dA / dB: Cin, H, W, in_up, in_sub; batch, Cout, dilation, padding
+ * mode, activation and output geometry from dA and equal in dB), so the pair costs one set of per-launch / per-workgroup
+ * fixed costs, one pass over the output and no residual read.  u_packed_cat: the two packed filter sets concatenated along
+ * the input-channel axis ([Cout/32][CinA + CinB][4][32][4]); bias: the SUM of the two biases (or NULL).  Cin % 8 == 0 for
+ * both, Cout % 64 == 0.  Rounding differs from the two-launch form only by the order of the fp32 accumulation. */
+int dvc_conv2d_winograd_dual(const DvcConvDesc* dA, const DvcConvDesc* dB, const float* xA, const float* xB,
+                             const float* u_packed_cat, const float* bias /* may be NULL */,
+                             const float* act_slope_ptr /* device scalar or NULL */, float* y,
+                             void* workspace /* or NULL */, size_t workspace_bytes, dvcStream stream);
 
 /* conv 1x1 with tiny Cout (<= 4) + optional tanh*128: ColorVidNet.conv10_ab, ColorVidNet.py:142-144.
  * w is the unpacked [Cout][Cin] matrix. */

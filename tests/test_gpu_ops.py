@@ -275,6 +275,45 @@ def test_conv2d_winograd(ops, case, cfg, split_k):
     assert (big[:, :8] == 3).all() and (big[:, 8 + Cout:] == 3).all()
 
 
+@pytest.mark.parametrize("N,CA,CB,Cout,H,W,upA,upB,act", [
+    (1, 512, 256, 256, 54, 96, 2, 1, 1),        # conv8_1(up(n7)) + conv3_3_short(n3)        (ColorVidNet.py:124-127)
+    (1, 256, 128, 128, 108, 192, 2, 1, 1),      # conv9_1 + conv2_2_short
+    (1, 128, 64, 128, 216, 384, 2, 1, 1),       # conv10_1 + conv1_2_short
+    (2, 16, 24, 64, 26, 46, 2, 1, 0),           # batch 2, half tiles on both edges (13 x 23 upsampled), no activation
+    (1, 8, 8, 64, 13, 24, 1, 1, 3),             # two inputs of the same size, LeakyReLU
+    (1, 64, 32, 128, 40, 30, 1, 2, 1),          # the SECOND input is the upsampled one
+])
+def test_conv2d_winograd_dual(ops, N, CA, CB, Cout, H, W, upA, upB, act):
+    """dvc_conv2d_winograd_dual — act(conv3x3(up_A(xA), W_A) + conv3x3(up_B(xB), W_B) + b_A + b_B) as one launch over the
+    channels of both inputs — against a float64 evaluation of the two reference convolutions and their sum (ColorVidNet.py:
+    124-139: `conv8_1(up(norm(c7_3))) + conv3_3_short(norm(c3_3))`), at the Winograd kernel's tolerance; deterministic; and
+    within fp32 rounding of the two-launch form (second convolution with the first one's output as its residual)."""
+    g = torch.Generator().manual_seed(N * 1000 + CA + CB + H)
+    xA = torch.randn(N, CA, H // upA, W // upA, generator=g)
+    xB = torch.randn(N, CB, H // upB, W // upB, generator=g)
+    wA = torch.randn(Cout, CA, 3, 3, generator=g) / (CA * 9) ** 0.5
+    wB = torch.randn(Cout, CB, 3, 3, generator=g) / (CB * 9) ** 0.5
+    bA, bB = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    up = lambda t, f: F.interpolate(t, scale_factor=f, mode="nearest") if f == 2 else t      # noqa: E731
+    ref = F.conv2d(up(xA.double(), upA), wA.double(), bA.double(), padding=1) + F.conv2d(up(xB.double(), upB), wB.double(), bB.double(), padding=1)
+    ref = {0: ref, 1: torch.relu(ref), 3: F.leaky_relu(ref, 0.2)}[act]
+    uA, uB = ops.pack_winograd_weight(wA.cuda()), ops.pack_winograd_weight(wB.cuda())
+    u = torch.cat((uA, uB), dim=1).contiguous()
+    b = (bA + bB).cuda()
+    got = ops.conv2d_winograd_dual(xA.cuda(), xB.cuda(), u, b, in_upA=upA, in_upB=upB, act=act, act_slope=0.2)
+    torch.cuda.synchronize()
+    e = relerr(got, ref)
+    two = ops.conv2d_winograd(xA.cuda(), uA, bA.cuda(), in_up=upA, act=act, act_slope=0.2,
+                              residual=ops.conv2d_winograd(xB.cuda(), uB, bB.cuda(), in_up=upB))
+    e2 = relerr(got, two.double().cpu())
+    report(f"conv2d_winograd_dual {CA}+{CB}->{Cout} {H}x{W} up {upA}/{upB} N={N}: rel_err vs fp64 {e:.2e}, vs the two-launch form {e2:.2e}")
+    assert e < 5e-5 and e2 < 5e-6
+    again = ops.conv2d_winograd_dual(xA.cuda(), xB.cuda(), u, b, in_upA=upA, in_upB=upB, act=act, act_slope=0.2)
+    assert torch.equal(again, got)
+    with pytest.raises(RuntimeError, match="virtual sizes"):
+        ops.conv2d_winograd_dual(xA.cuda(), xB.cuda()[:, :, :-2].contiguous(), u, b, in_upA=upA, in_upB=upB)
+
+
 def test_conv2d_channel_slice_output(ops):
     """y may be a channel slice of a wider tensor (WarpNet concat, NonlocalNet.py:464)."""
     g = torch.Generator().manual_seed(5)
