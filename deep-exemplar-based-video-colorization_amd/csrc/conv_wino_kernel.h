@@ -276,12 +276,22 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
         (unsigned)(size_t)(CONV_AS3 float*)xsb + (hi * plane + (2 * (wn * TR + tr) + ph) * PITCH + 2 * tc) * 4;
     const unsigned ulane = (unsigned)(size_t)(CONV_AS3 float*)usb + (((wm * KC + hi) * 4 + 2 * ph) * 32 + l31) * 16;
 
+    // No control flow at the chunk boundaries: each one issues exactly one more chunk — the range's last chunk again, into a
+    // buffer nobody reads any more, once the range is exhausted — so the waits are compile-time constants and the K loop is
+    // one basic block (VAR 3 keeps the conditional issues / waits it replaced, for A/B: profiles/r03_conv_wino_branch_free.txt)
+    constexpr bool BRANCH_FREE = VAR != 3;
     issue_x(c_begin, 0);      // (the chunk's filter half is already in flight; NI instructions per chunk either way)
-    if (c_begin + 1 < c_end) issue(c_begin + 1, 1);
-    if (c_begin + 2 < c_end) issue(c_begin + 2, 2);
-    if (c_begin + 2 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
-    else if (c_begin + 1 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (BRANCH_FREE) {
+        issue(min(c_begin + 1, c_end - 1), 1);
+        issue(min(c_begin + 2, c_end - 1), 2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+    } else {
+        if (c_begin + 1 < c_end) issue(c_begin + 1, 1);
+        if (c_begin + 2 < c_end) issue(c_begin + 2, 2);
+        if (c_begin + 2 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+        else if (c_begin + 1 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 
     const float slope = a.act_slope_ptr ? *a.act_slope_ptr : a.act_slope;
@@ -365,6 +375,11 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
                 WINO_MFMA(0, U[cs][0].x, V03[cs][0].x);
                 if (!last) {
                     WINO_LOADS(D[ns], U[ns], xb + (ks + 1) * (2 * plane * 4), ub, (ks + 1) * 4096);
+                } else if (BRANCH_FREE) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    issue(min(c + 3, c_end - 1), buf);
+                    WINO_LOADS(D[ns], U[ns], xbn, ubn, 0);
                 } else if (more) {
                     if (c + 2 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -494,6 +509,15 @@ template <int WM, int WN, int KC>
 static void conv_wino_launch_shape(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s) {
     constexpr int NT = 128 * WM * WN;
 #ifdef DVC_DEBUG
+    if (s.k.dbg & 8) {      // dvc_debug_conv_variant(8): conditional chunk issues / waits in the K loop (A/B only)
+        switch (tr) {
+            case 1: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 1, KC, 3>), grid, dim3(NT), 0, st, s); break;
+            case 2: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 2, KC, 3>), grid, dim3(NT), 0, st, s); break;
+            case 4: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 4, KC, 3>), grid, dim3(NT), 0, st, s); break;
+            default: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 8, KC, 3>), grid, dim3(NT), 0, st, s); break;
+        }
+        return;
+    }
     if (s.k.dbg & 32) {     // dvc_debug_conv_variant(32): write-through output stores (A/B only)
         switch (tr) {
             case 1: hipLaunchKernelGGL((conv_wino_kernel<WM, WN, 1, KC, 2>), grid, dim3(NT), 0, st, s); break;
