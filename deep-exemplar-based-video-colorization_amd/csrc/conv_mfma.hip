@@ -96,6 +96,8 @@ static constexpr int g_conv_dbg = 0;
 static constexpr long long* g_conv_dbg_buf = nullptr;
 #endif
 
+bool conv_image_launch(const ConvKArgs& a, hipStream_t st);      // conv_image.hip
+
 // One launch (plus its reduce / fixup) for the d->N images at x / y.  The PLAN — tile configuration, split over input
 // channels, stream-K ranges — is always the single-image plan: an image's result never depends on what else is in the
 // batch, and a batch of N is bit-identical to N single-image calls (the clip driver batches look-ahead front ends on that).
@@ -144,6 +146,12 @@ static int conv2d_images(const DvcConvDesc* d, const float* x, const float* w_pa
     a.dbg = g_conv_dbg;
     a.dbg_buf = g_conv_dbg_buf;
 
+    // the two image-input layers (3 -> 64, 7 -> 32) have a kernel of their own (conv_image.hip); an explicit cfg / split_k keeps
+    // the general engine reachable (tests, tools/conv_algo_sweep.py)
+    if (d->cfg < 0 && d->split_k == 0 && !(g_conv_dbg & 1024) && conv_image_launch(a, (hipStream_t)stream)) {
+        DVC_CHECK_LAUNCH("dvc_conv2d(image-input layer)");
+        return 0;
+    }
     const int tw = pick_tw(OW);
     const int rpt = 32 / tw;
     // stride 1: geometry is baked into the kernel (one variant per ksize/dilation); stride 2 (and a

@@ -411,6 +411,11 @@ def _tune_conv(lib, d, tensors):
         e1.synchronize()
         return e0.elapsed_time(e1)
 
+    # the library's own choice first: it is the only way to the kernels that are not a (cfg, split_k) of the general engine
+    # (the image-input layers, csrc/conv_image.hip)
+    d.cfg, d.split_k = -1, 0
+    if launch() == 0:
+        best, best_t = (-1, 0), time_it()
     # (layers without a fused input transform stage through LDS-DMA; forcing register staging, cfg 16 + k,
     # never won in the per-layer sweep, so it is not a candidate)
     for cfg in (0, 1, 2, 3, 4):

@@ -123,6 +123,43 @@ def test_conv2d(ops, case, cfg):
     assert e < 2e-5, (name, cfg, e)  # fp32 accumulation over <= 2304 terms
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,pad_mode,affine,bias,act", [
+    (1, 3, 64, 216, 384, 0, True, True, 1),        # VGG19 conv1_1 with vgg_preprocess folded in (NonlocalNet.py:235, util.py:347-352)
+    (1, 7, 32, 216, 384, 0, False, True, 1),       # ColorVidNet conv1_1[0] (ColorVidNet.py:98)
+    (2, 3, 64, 37, 45, 0, True, True, 1),          # ragged tiles on both edges, batch 2 (per-image affine)
+    (3, 7, 32, 13, 70, 1, False, False, 3),        # reflect padding, no bias, LeakyReLU
+    (1, 3, 64, 8, 32, 0, False, True, 0),          # exactly one tile
+    (1, 7, 32, 5, 3, 0, True, True, 2),            # smaller than a tile, PReLU slope from a device scalar
+])
+def test_conv2d_image_layers(ops, N, Cin, Cout, H, W, pad_mode, affine, bias, act):
+    """The image-input layers' own kernel (csrc/conv_image.hip, taken by dvc_conv2d's automatic choice for 3 -> 64 and 7 -> 32,
+    3x3 / stride 1 / pad 1): the fp64 reference at the direct engine's tolerance, equal within fp32 rounding to the general
+    engine (cfg = 3), deterministic, destination may be a channel slice, bytes around it untouched."""
+    g = torch.Generator().manual_seed(N * 100 + Cin + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1 if bias else None
+    scale = torch.rand(N * Cin, generator=g) + 0.5 if affine else None
+    shift = torch.randn(N * Cin, generator=g) * 0.3 if affine else None
+    ref = ref_conv(x, w, b, 3, 1, 1, 1, pad_mode, 1, 1, scale, shift, None, None, act, 0.2)
+    cu = lambda t: None if t is None else t.cuda()      # noqa: E731
+    slope_t = torch.tensor([0.2], device="cuda") if act == 2 else None
+    big = torch.full((N, Cout + 16, H, W), 3.0, device="cuda")
+    kw = dict(pad_mode=pad_mode, act=act, act_slope=0.2, act_slope_t=slope_t, in_scale=cu(scale), in_shift=cu(shift))
+    wp = ops.pack_conv_weight(w.cuda())
+    ops.conv2d(x.cuda(), wp, cu(b), out=big[:, 8:8 + Cout], out_batch_stride=(Cout + 16) * H * W, **kw)
+    y1 = big[:, 8:8 + Cout].clone()
+    big[:, 8:8 + Cout] = -7.0
+    ops.conv2d(x.cuda(), wp, cu(b), out=big[:, 8:8 + Cout], out_batch_stride=(Cout + 16) * H * W, **kw)
+    general = ops.conv2d(x.cuda(), wp, cu(b), cfg=3, **kw)
+    torch.cuda.synchronize()
+    e, eg = relerr(y1, ref), relerr(y1, general.double().cpu())
+    report(f"conv2d image layer {Cin}->{Cout} {H}x{W} N={N} pad_mode={pad_mode}: rel_err vs fp64 {e:.2e}, vs the general engine {eg:.2e}")
+    assert e < 2e-5 and eg < 2e-6
+    assert torch.equal(y1, big[:, 8:8 + Cout])
+    assert (big[:, :8] == 3).all() and (big[:, 8 + Cout:] == 3).all()
+
+
 @pytest.mark.parametrize("split_k", [1, 2, 3, 4, 6, 8])
 def test_conv2d_split_k(ops, split_k):
     """Split-K (partial sums + fixed-order reduce) gives the same result as the single-pass kernel, with
