@@ -15,6 +15,8 @@
 // wave's current row and supplies the B operand of k = 2 step + (lane >> 5) with one ds_read; the filter values a lane
 // supplies as A operand (channel lane & 31 of each 32-channel block, same k) are the same for every pixel block, so each wave
 // loads them ONCE into registers: w_packed is [Cin][9][Cout] = [k][Cout], the lane's values are a strided column of it.
+#include <type_traits>
+
 #include "conv_kernel.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -41,25 +43,46 @@ __global__ __launch_bounds__(256) void conv_image_kernel(ConvKArgs a, int tiles_
             wreg[b][s] = k < K ? a.w[k * Cout + b * 32 + l31] : 0.f;
         }
 
+    // the lane's 16 output channels per block are (r & 3) + 8 (r >> 2) + 4 hi: their bias values too are loaded once
+    float breg[NBLK][16];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) breg[b][r] = a.bias ? a.bias[b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] : 0.f;
+
+    // patch staging: the index arithmetic of a patch position is shared by the CIN planes, all their loads are in flight together
     const float* xn = a.x + (long)n * a.x_bs;
     const int HW = a.H * a.W;
-    for (int e = tid; e < CIN * PR * (TW + 2); e += 256) {
-        const int c = e / (PR * (TW + 2)), rem = e - c * (PR * (TW + 2));
-        const int iy = rem / (TW + 2), ix = rem - iy * (TW + 2);
-        const int o = stored_offset(a, ty0 - 1 + iy, tx0 - 1 + ix);
-        float v = 0.f;
-        if (o >= 0) {
-            v = xn[c * HW + o];
-            if (a.in_scale) v = v * a.in_scale[n * CIN + c] + a.in_shift[n * CIN + c];
+    float sc[CIN], sh[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+        sc[c] = a.in_scale ? a.in_scale[n * CIN + c] : 1.f;      // (x * 1 + 0 == x exactly)
+        sh[c] = a.in_scale ? a.in_shift[n * CIN + c] : 0.f;
+    }
+    constexpr int PE = PR * (TW + 2);
+#pragma unroll
+    for (int it = 0; it < (PE + 255) / 256; ++it) {
+        const int e = tid + it * 256;
+        const int iy = e / (TW + 2), ix = e - iy * (TW + 2);
+        const int o = e < PE ? stored_offset(a, ty0 - 1 + iy, tx0 - 1 + ix) : -1;
+        float v[CIN];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) v[c] = xn[c * HW + max(o, 0)];
+        if (e < PE) {
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) patch[c * PLANE + iy * PITCH + ix] = o >= 0 ? v[c] * sc[c] + sh[c] : 0.f;
         }
-        patch[c * PLANE + iy * PITCH + ix] = v;
     }
     __syncthreads();
 
     const float slope = a.act_slope_ptr ? *a.act_slope_ptr : a.act_slope;
-    const long OHW = (long)a.OH * a.OW;
+    const int OHW = a.OH * a.OW;                            // (the launcher checks Cout * OH * OW < 2^31)
     float* yn = a.y + (long)n * a.y_bs;
     const int ox = tx0 + l31;
+    // activation without control flow in the store loop: v > 0 ? v : v * neg (ReLU: neg = 0 and the product is replaced by 0;
+    // none: neg = 1); tanh (nothing on the path uses it here) takes the general function
+    const bool relu = a.act == DVC_ACT_RELU, general_act = a.act == DVC_ACT_TANH128;
+    const float neg = (a.act == DVC_ACT_PRELU || a.act == DVC_ACT_LEAKY) ? slope : 1.f;
 #pragma unroll
     for (int rr = 0; rr < TH / 4; ++rr) {
         const int row = wave + 4 * rr;                      // the wave's pixel block: row `row` of the tile, 32 pixels
@@ -72,10 +95,9 @@ __global__ __launch_bounds__(256) void conv_image_kernel(ConvKArgs a, int tiles_
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             // k = 2 s + hi -> (ci, ky, kx); a padded k reads element 0 of the patch against a zero filter value
-            constexpr int nk = 2;
-            int off[nk];
+            int off[2];
 #pragma unroll
-            for (int h = 0; h < nk; ++h) {
+            for (int h = 0; h < 2; ++h) {
                 const int k = 2 * s + h;
                 off[h] = k < K ? (k / 9) * PLANE + ((k % 9) / 3) * PITCH + (k % 3) : 0;
             }
@@ -85,14 +107,20 @@ __global__ __launch_bounds__(256) void conv_image_kernel(ConvKArgs a, int tiles_
         }
         const int oy = ty0 + row;
         if (oy < a.OH && ox < a.OW) {
+            float* yp = yn + (4 * hi) * OHW + oy * a.OW + ox;
+            auto store_all = [&](auto GENERAL) {
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b)
+                for (int b = 0; b < NBLK; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    float v = acc[b][r] + (a.bias ? a.bias[co] : 0.f);
-                    yn[(long)co * OHW + (long)oy * a.OW + ox] = apply_act(v, a.act, slope);
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[b][r] + breg[b][r];
+                        if (decltype(GENERAL)::value) v = apply_act(v, a.act, slope);
+                        else v = v > 0.f ? v : (relu ? 0.f : v * neg);
+                        yp[(b * 32 + (r & 3) + 8 * (r >> 2)) * OHW] = v;
+                    }
+            };
+            if (general_act) store_all(std::true_type{});
+            else store_all(std::false_type{});
         }
     }
 #endif
@@ -102,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_image_kernel(ConvKArgs a, int tiles_
 bool conv_image_launch(const ConvKArgs& a, hipStream_t st) {
     if (a.ks != 3 || a.stride != 1 || a.dil != 1 || a.pad != 1 || a.in_up != 1 || a.in_sub != 1 || a.in_prelu || a.res) return false;
     const int tiles_x = (a.OW + 31) / 32, tiles_y = (a.OH + 7) / 8;
-    if ((long)tiles_x * tiles_y >= (1L << 31) || a.N > 65535) return false;
+    if ((long)tiles_x * tiles_y >= (1L << 31) || a.N > 65535 || (long)a.Cout * a.OH * a.OW >= (1L << 31)) return false;
     const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)a.N);
     if (a.Cin == 3 && a.Cout == 64)
         hipLaunchKernelGGL((conv_image_kernel<3, 2>), grid, dim3(256), 0, st, a, tiles_x);
