@@ -72,6 +72,61 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
     }
 }
 
+// split-K second stage with the 2x2 / stride-2 max pool fused (dvc_conv2d_winograd_pool): thread = one pooling window of one
+// channel = 2 rows x float2 of every slice; the sums are conv_splitk_reduce_kernel's (same order, same arithmetic), y (when not
+// NULL) gets them, `pool` their maximum when the whole window is inside the image (floor mode, as nn.MaxPool2d(2, 2)).
+__global__ __launch_bounds__(256) void conv_splitk_reduce_pool_kernel(const float* __restrict__ part, int S, long slab, int Cout, int OH,
+                                                                      int OW, const float* __restrict__ bias, int act, float act_slope,
+                                                                      const float* __restrict__ act_slope_ptr, float* __restrict__ y,
+                                                                      long y_bs, float* __restrict__ pool, long pool_bs) {
+    const float slope = act_slope_ptr ? *act_slope_ptr : act_slope;
+    const int WH = (OH + 1) >> 1, WW = (OW + 1) >> 1;      // windows incl. the partial ones on an odd edge (they only feed y)
+    const int n = blockIdx.y;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)Cout * WH * WW) return;
+    const int wx = (int)(t % WW), wy = (int)((t / WW) % WH), co = (int)(t / ((long)WW * WH));
+    const long OHW = (long)OH * OW, per_img = (long)Cout * OHW;
+    const float b = bias ? bias[co] : 0.f;
+    const bool pair = (OW & 1) == 0;                        // the window's two columns are one aligned float2
+    float v[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = 2 * wy + r;
+        v[r][0] = v[r][1] = 0.f;
+        if (oy >= OH) continue;
+        const float* p0 = part + (long)n * per_img + (long)co * OHW + (long)oy * OW + 2 * wx;
+        float2 tt[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            tt[s] = make_float2(0.f, 0.f);
+            if (s < S) {
+                if (pair) tt[s] = *reinterpret_cast<const float2*>(p0 + (long)s * slab);
+                else {
+                    tt[s].x = p0[(long)s * slab];
+                    if (2 * wx + 1 < OW) tt[s].y = p0[(long)s * slab + 1];
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {       // S <= 8, fixed order
+            v[r][0] += tt[s].x;
+            v[r][1] += tt[s].y;
+        }
+        v[r][0] = apply_act(v[r][0] + b, act, slope);
+        v[r][1] = apply_act(v[r][1] + b, act, slope);
+        if (y) {
+            float* yo = y + (long)n * y_bs + (long)co * OHW + (long)oy * OW + 2 * wx;
+            if (pair) *reinterpret_cast<float2*>(yo) = make_float2(v[r][0], v[r][1]);
+            else {
+                yo[0] = v[r][0];
+                if (2 * wx + 1 < OW) yo[1] = v[r][1];
+            }
+        }
+    }
+    if (2 * wy + 1 < OH && 2 * wx + 1 < OW)
+        pool[(long)n * pool_bs + ((long)co * (OH >> 1) + wy) * (OW >> 1) + wx] = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
+}
+
 // compute units of the current device (256 on MI355X), queried once
 static int conv_num_cus() {
     static int n = 0;
@@ -508,8 +563,8 @@ extern "C" int dvc_conv2d_winograd_split(const DvcConvDesc* d, size_t workspace_
 // input's geometry, `d2` the second input's (Cin, H, W, in_up, in_sub).
 static int wino_run(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x, const float* x2, const float* u_packed,
                     const float* bias, const float* act_slope_ptr, const float* residual, float* y, void* workspace,
-                    size_t workspace_bytes, dvcStream stream) {
-    DVC_REQUIRE(d && x && u_packed && y, "dvc_conv2d_winograd: null argument");
+                    size_t workspace_bytes, dvcStream stream, float* pool = nullptr, long pool_batch_stride = 0) {
+    DVC_REQUIRE(d && x && u_packed && (y || pool), "dvc_conv2d_winograd: null argument");
     DVC_REQUIRE(d->ksize == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil,
                 "dvc_conv2d_winograd: needs a 3x3 stride-1 layer with pad == dilation (1 or 2)");
     DVC_REQUIRE(!d->in_prelu, "dvc_conv2d_winograd: no fused input transform on this path");
@@ -582,12 +637,14 @@ static int wino_run(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x,
                 "dvc_conv2d_winograd: DVC_CONV_DEFER_REDUCE needs a workspace that holds the partial sums of the whole batch");
     DVC_REQUIRE(!(d->flags & DVC_CONV_DEFER_REDUCE) || a.split == 1 || !residual,
                 "dvc_conv2d_winograd: DVC_CONV_DEFER_REDUCE does not carry a residual");
+    s.pool_bs = pool_batch_stride ? pool_batch_stride : (long)d->Cout * (OH / 2) * (OW / 2);
     for (int n0 = 0; n0 < d->N; n0 += group) {
         const int NB = std::min(group, d->N - n0);
         a.N = NB;
         a.x = x + (long)n0 * a.x_bs;
         if (d2) s.x2 = x2 + (long)n0 * s.x2_bs;
-        a.y = y + (long)n0 * a.y_bs;
+        a.y = y ? y + (long)n0 * a.y_bs : nullptr;
+        s.pool = pool ? pool + (long)n0 * s.pool_bs : nullptr;
         a.res = residual ? residual + (long)n0 * a.res_bs : nullptr;
         s.gz = NB * a.split;
         DVC_REQUIRE((long)s.gx * s.gy * s.gz < (1L << 31), "dvc_conv2d_winograd: grid too large");
@@ -603,7 +660,13 @@ static int wino_run(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x,
         else if (best_m == 2) conv_wino_launch_m1(best_tr, grid, st, s);
         else conv_wino_launch_m0(best_tr, grid, st, s);
         DVC_CHECK_LAUNCH("dvc_conv2d_winograd");
-        if (a.split > 1 && !(d->flags & DVC_CONV_DEFER_REDUCE)) {
+        if (a.split > 1 && pool) {
+            const long windows = (long)d->Cout * ((OH + 1) / 2) * ((OW + 1) / 2);
+            hipLaunchKernelGGL(conv_splitk_reduce_pool_kernel, dim3((unsigned)((windows + 255) / 256), NB), dim3(256), 0, st, a.part,
+                               a.split, (long)NB * per_img, d->Cout, OH, OW, bias, d->act, d->act_slope, act_slope_ptr, a.y, a.y_bs,
+                               s.pool, s.pool_bs);
+            DVC_CHECK_LAUNCH("dvc_conv2d_winograd_pool(split-K reduce)");
+        } else if (a.split > 1 && !(d->flags & DVC_CONV_DEFER_REDUCE)) {
             const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)NB * per_img) % 4 == 0);
             if (v4)
                 hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)((per_img / 4 + 255) / 256), NB), dim3(256), 0, st,
@@ -623,6 +686,18 @@ extern "C" int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const f
                                    const float* act_slope_ptr, const float* residual, float* y, void* workspace,
                                    size_t workspace_bytes, dvcStream stream) {
     return wino_run(d, nullptr, x, nullptr, u_packed, bias, act_slope_ptr, residual, y, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dvc_conv2d_winograd_pool(const DvcConvDesc* d, const float* x, const float* u_packed, const float* bias,
+                                        const float* act_slope_ptr, float* y, float* y_pool, int64_t pool_batch_stride,
+                                        void* workspace, size_t workspace_bytes, dvcStream stream) {
+    DVC_REQUIRE(d && y_pool, "dvc_conv2d_winograd_pool: null argument");
+    DVC_REQUIRE(d->dil == 1 && !(d->flags & DVC_CONV_DEFER_REDUCE), "dvc_conv2d_winograd_pool: dilation 1, no deferred reduce");
+    int32_t OH = 0, OW = 0;
+    dvc_conv2d_out_hw(d, &OH, &OW);
+    DVC_REQUIRE(OH >= 2 && OW >= 2, "dvc_conv2d_winograd_pool: output smaller than a pooling window");
+    return wino_run(d, nullptr, x, nullptr, u_packed, bias, act_slope_ptr, nullptr, y, workspace, workspace_bytes, stream, y_pool,
+                    pool_batch_stride);
 }
 
 extern "C" int dvc_conv2d_winograd_dual(const DvcConvDesc* dA, const DvcConvDesc* dB, const float* xA, const float* xB,

@@ -63,6 +63,11 @@ struct ConvWinoArgs {
     const float* x2;
     long x2_bs;
     int cinA, H2, W2, VH2, VW2, in_up2, in_sub2;
+    // dvc_conv2d_winograd_pool: the 2x2 / stride-2 max pool of the activated output, [N][Cout][OH/2][OW/2] (a lane's 2x2 output
+    // tile IS a pooling window).  Unsplit launches write it from the epilogue (and skip y when k.y is NULL); split launches leave
+    // it to the reduce kernel.
+    float* pool;
+    long pool_bs;
 };
 __host__ __device__ __forceinline__ unsigned wino_magic(long d) {      // (d == 1: 2^32 does not fit; 0 means "quotient = n")
     return d > 1 ? (unsigned)(((1ULL << 32) + (unsigned long long)d - 1) / (unsigned long long)d) : 0u;
@@ -459,6 +464,9 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
         const int ox0 = ss * x0 + px, ox1 = ss * (x0 + 1) + px;
         const bool okx0 = ox0 < a.OW, okx1 = ox1 < a.OW;
         const bool pairst = ss == 1 && okx1 && (a.OW & 1) == 0;      // the two columns are one aligned float2
+        const bool pool_here = !partial && s.pool;                   // (wave-uniform; the launcher guarantees ss == 1 then)
+        float* pb = pool_here ? s.pool + (long)n * s.pool_bs : nullptr;
+        const long PHW = (long)(a.OH >> 1) * (a.OW >> 1);
         for8([&](auto IC) {
             constexpr int i = decltype(IC)::value;
             constexpr int r = 8 * PH + i;
@@ -471,6 +479,7 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
             }
             const int co = (b0 + wm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             const float bias = (!partial && a.bias) ? a.bias[co] : 0.f;
+            float pooled = 0.f;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int oy = p ? oy1 : oy0;
@@ -484,6 +493,12 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
                 if (!partial) {
                     v0 = apply_act(v0, a.act, slope);
                     v1 = apply_act(v1, a.act, slope);
+                }
+                if (pool_here) {
+                    const float m = fmaxf(v0, v1);
+                    pooled = p ? fmaxf(pooled, m) : m;
+                    if (p && okx1) pb[(long)co * PHW + (long)(oy0 >> 1) * (a.OW >> 1) + (ox0 >> 1)] = pooled;   // (oy1 < OH here)
+                    if (!a.y) continue;
                 }
                 if (pairst && VAR == 2) {
                     // write-through (sc1) stores: the lines leave the XCD's L2 while the kernel runs instead of in the

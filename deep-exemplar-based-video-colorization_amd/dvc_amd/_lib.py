@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DVC_DEBUG_LIB=1 (tools/ only) loads the -DDVC_DEBUG build, the only one that carries the dvc_debug_* hooks
 DEBUG_BUILD = os.environ.get("DVC_DEBUG_LIB", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "libdvc_hip_debug.so" if DEBUG_BUILD else "libdvc_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -43,6 +43,8 @@ SIGNATURES = {
                                                 ctypes.POINTER(c_i32)]),
     "dvc_conv2d_winograd": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                            ctypes.c_size_t, _VP]),
+    "dvc_conv2d_winograd_pool": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, c_i64, _VP,
+                                                ctypes.c_size_t, _VP]),
     "dvc_conv2d_winograd_dual": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP,
                                                 _VP, _VP, ctypes.c_size_t, _VP]),
     "dvc_conv1x1_small": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, _VP, _VP]),

@@ -23,6 +23,11 @@ import torch
 from . import nets, ops
 
 
+def _epoch():
+    """Everything that decides WHICH launches a sequence consists of."""
+    return (nets.pack_epoch(), ops.conv_algo(), ops.fuse_reduce(), ops.pool_fusion(), ops.dual_conv_enabled(), ops.autotune_enabled())
+
+
 class CapturedSequence:
     """`fn()` (no arguments: it closes over its static input tensors) captured on `stream`; `.out` is whatever `fn`
     returned at capture time (tensors at fixed addresses, overwritten by every replay)."""
@@ -35,14 +40,14 @@ class CapturedSequence:
             with torch.cuda.stream(stream):
                 fn()                                  # eager warm-up: packs weights, tunes convolutions, sizes workspaces
             stream.synchronize()
-            self.epoch = (nets.pack_epoch(), ops.conv_algo(), ops.fuse_reduce(), ops.autotune_enabled())
+            self.epoch = _epoch()
             with torch.cuda.graph(self.graph, stream=stream):
                 self.out = fn()
-        if (nets.pack_epoch(), ops.conv_algo(), ops.fuse_reduce(), ops.autotune_enabled()) != self.epoch:
+        if _epoch() != self.epoch:
             raise RuntimeError("dvc_amd.graph: a weight was packed during stream capture (warm-up did not cover the sequence)")
 
     def stale(self):
-        return (nets.pack_epoch(), ops.conv_algo(), ops.fuse_reduce(), ops.autotune_enabled()) != self.epoch
+        return _epoch() != self.epoch
 
     def replay(self):
         """One hipGraphLaunch on the current stream."""

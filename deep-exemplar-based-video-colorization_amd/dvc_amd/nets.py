@@ -144,11 +144,23 @@ class VGG19_pytorch(nn.Module):
         out = {}
         cur = x
         conv_names = {("r%s" % n[4:].replace("_", "")): n for n, _, _ in arch.VGG_CONVS}
+        pooled = None
         for i, key in enumerate(arch.VGG_KEYS):
             if i > last:
                 break  # the reference always runs through p5; the requested outputs are identical
             if key[0] == "p":
-                cur = ops.maxpool2x2(cur) if self._pool == "max" else ops.avgpool2x2(cur)
+                if pooled is not None:          # came out of the convolution in front of it (ops.conv2d_winograd_pool)
+                    cur, pooled = pooled, None
+                else:
+                    cur = ops.maxpool2x2(cur) if self._pool == "max" else ops.avgpool2x2(cur)
+            elif (self._pool == "max" and ops.pool_fusion() and i + 1 <= last and arch.VGG_KEYS[i + 1][0] == "p"
+                  and min(cur.shape[2:]) >= 2
+                  and ops.winograd_selected(N, cur.shape[1], cur.shape[2], cur.shape[3], getattr(self, conv_names[key]).weight.shape[0])):
+                # relu1_2 / relu2_2 / relu3_4 / relu4_4 -> pool: the pooled tensor comes out of the convolution's own launch; the
+                # full-resolution one only when somebody asked for it
+                conv = getattr(self, conv_names[key])
+                cur, pooled = ops.conv2d_winograd_pool(cur, _packs(self._cache, conv_names[key], conv.weight)("winograd"),
+                                                       conv.bias.detach(), act=ops.ACT_RELU, want_full=key in out_keys)
             else:
                 name = conv_names[key]
                 conv = getattr(self, name)

@@ -269,6 +269,41 @@ def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_
     return out
 
 
+_pool_fusion = _os.environ.get("DVC_POOL_FUSION", "1") != "0"
+
+
+def pool_fusion():
+    return _pool_fusion
+
+
+def set_pool_fusion(flag=True):
+    global _pool_fusion
+    _pool_fusion = bool(flag)
+
+
+def conv2d_winograd_pool(x, u_packed, bias, *, act=ACT_NONE, act_slope=0.0, act_slope_t=None, pad_mode=PAD_ZERO, want_full=True):
+    """dvc_conv2d_winograd_pool: (act(conv3x3(x)), maxpool2x2 of it) from one convolution launch (+ its reduce when the layer is
+    split); the full-resolution tensor is None with want_full=False.  Bit-identical to conv2d_winograd -> maxpool2x2."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (u_packed, "u_packed"), (bias, "bias"), (act_slope_t, "act_slope")):
+        _need(t, nm)
+    N, Cin, H, W = x.shape
+    assert u_packed.dim() == 5 and u_packed.shape[1] == Cin and tuple(u_packed.shape[2:]) == (4, 32, 4), u_packed.shape
+    Cout = u_packed.shape[0] * 32
+    d = DvcConvDesc(N, Cin, H, W, Cout, 3, 1, 1, 1, pad_mode, 1, 1, act, float(act_slope), 0, -1, 0, 0, 0, 0, 0)
+    if conv_record is not None:
+        conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=3, stride=1, dil=1, pad=1, pad_mode=pad_mode,
+                                in_up=1, in_sub=1, affine=False, in_prelu=False, residual=False, act=act, algo="winograd"))
+    ws = _workspace(x.device, CONV_WORKSPACE_BYTES, "conv")
+    _bump_generation(ws)
+    full = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.float32) if want_full else None
+    pooled = torch.empty((N, Cout, H // 2, W // 2), device=x.device, dtype=torch.float32)
+    _lib.check(lib.dvc_conv2d_winograd_pool(ctypes.byref(d), _p(x), _p(u_packed), _p(bias), _p(act_slope_t), _p(full), _p(pooled), 0,
+                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+               "dvc_conv2d_winograd_pool")
+    return full, pooled
+
+
 def conv2d_winograd_dual(xA, xB, u_cat, bias, *, dil=1, pad_mode=PAD_ZERO, in_upA=1, in_upB=1, act=ACT_NONE, act_slope=0.0,
                          act_slope_t=None):
     """dvc_conv2d_winograd_dual: act(conv3x3(up_A(xA), W_A) + conv3x3(up_B(xB), W_B) + bias) in one launch.  u_cat = the two

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 10
+#define DVC_ABI_VERSION 11
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -131,6 +131,14 @@ int dvc_conv2d_winograd(const DvcConvDesc* d, const float* x, const float* u_pac
                         const float* bias /* may be NULL */, const float* act_slope_ptr /* device scalar or NULL */,
                         const float* residual /* or NULL */, float* y,
                         void* workspace /* or NULL */, size_t workspace_bytes, dvcStream stream);
+/* dvc_conv2d_winograd with nn.MaxPool2d(2, 2) of the activated output fused (VGG19: relu1_2 -> pool, relu2_2 -> pool, relu3_4 ->
+ * pool, relu4_4 -> pool, /root/reference/models/NonlocalNet.py:240-254): y_pool [N][Cout][OH/2][OW/2] (floor mode;
+ * pool_batch_stride in elements, 0 = dense) is written by the convolution's epilogue — a lane's 2x2 Winograd output tile is a
+ * pooling window — or, when the layer is split over its input channels, by the reduce kernel.  y may be NULL when only the pooled
+ * tensor is wanted.  Both outputs are bit-identical to dvc_conv2d_winograd followed by dvc_maxpool2x2.  Dilation 1, no residual. */
+int dvc_conv2d_winograd_pool(const DvcConvDesc* d, const float* x, const float* u_packed, const float* bias /* may be NULL */,
+                             const float* act_slope_ptr /* device scalar or NULL */, float* y /* or NULL */, float* y_pool,
+                             int64_t pool_batch_stride, void* workspace /* or NULL */, size_t workspace_bytes, dvcStream stream);
 /* TWO 3x3 convolutions whose outputs are added, as ONE launch: y = act(conv(T_A(xA), W_A) + conv(T_B(xB), W_B) + bias).
  * ColorVidNet.py:124-139 adds a skip convolution to the first convolution of every decoder block
  * (conv8_1(up(norm(c7_3))) + conv3_3_short(norm(c3_3)), likewise conv9_1 / conv10_1): the reduction simply runs over the

@@ -68,6 +68,27 @@ def test_vgg19_all_keys(nets, weights, H, W):
     assert rel(got2, ref2) < 1e-4
 
 
+@pytest.mark.parametrize("H,W", [(216, 384), (54, 90)])
+def test_vgg19_pool_fused_into_the_convolution(nets, H, W):
+    """relu1_2 / relu2_2 / relu3_4 / relu4_4 -> pool come out of the convolution's own launch (ops.conv2d_winograd_pool): every
+    requested activation is bit-identical to the convolution -> maxpool2x2 sequence, whether the pre-pool tensor is itself
+    requested (r12, r22: the front end's taps; r34) or not."""
+    from dvc_amd import ops, synth
+    from oracle import dvc_oracle as O
+    vgg = nets[0]
+    x = O.gray2rgb_batch(synth.synth_lab(7, H, W)[:, 0:1]).cuda()
+    for keys in (["r12", "r22", "r32", "r42", "r52"], ["r34", "p3", "r44", "p4"], ["p1"]):
+        assert ops.pool_fusion()
+        fused = vgg(x, keys)
+        try:
+            ops.set_pool_fusion(False)
+            plain = vgg(x, keys)
+        finally:
+            ops.set_pool_fusion(True)
+        for k, a, b in zip(keys, fused, plain):
+            assert torch.equal(a, b), k
+
+
 def test_vgg_avgpool_variant(weights):
     from models.NonlocalNet import VGG19_pytorch
     from oracle import dvc_oracle as O

@@ -312,6 +312,34 @@ def test_conv2d_winograd(ops, case, cfg, split_k):
     assert (big[:, :8] == 3).all() and (big[:, 8 + Cout:] == 3).all()
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,act,want_full", [
+    (1, 64, 64, 216, 384, 1, True),        # VGG19 conv1_2 -> relu1_2 (a feature tap) -> pool   (NonlocalNet.py:240-242)
+    (1, 128, 128, 108, 192, 1, True),      # conv2_2 -> relu2_2 -> pool
+    (1, 256, 256, 54, 96, 1, False),       # conv3_4 -> pool: split over input channels, only the pooled tensor is wanted
+    (1, 512, 512, 27, 48, 1, False),       # conv4_4 -> pool: odd height, the last row belongs to no window
+    (2, 64, 128, 13, 25, 3, True),         # batch 2, odd width, LeakyReLU
+    (1, 512, 64, 27, 47, 0, True),         # split, odd both ways, no activation, full tensor wanted
+    (3, 8, 64, 2, 2, 1, True),             # exactly one window
+])
+def test_conv2d_winograd_pool(ops, N, Cin, Cout, H, W, act, want_full):
+    """dvc_conv2d_winograd_pool: the 2x2 max pool written by the convolution's own launch (epilogue, or the reduce kernel of a
+    split layer) — both outputs BIT-identical to dvc_conv2d_winograd followed by dvc_maxpool2x2, and the pool equal to
+    F.max_pool2d of the convolution output (floor mode: nn.MaxPool2d(2, 2), NonlocalNet.py:242)."""
+    g = torch.Generator().manual_seed(Cin + Cout + H + W)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    u = ops.pack_winograd_weight((torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda())
+    b = torch.randn(Cout, generator=g).cuda()
+    want = ops.conv2d_winograd(x, u, b, act=act, act_slope=0.2)
+    want_pool = ops.maxpool2x2(want)
+    assert torch.equal(want_pool, F.max_pool2d(want, 2, 2))
+    full, pooled = ops.conv2d_winograd_pool(x, u, b, act=act, act_slope=0.2, want_full=want_full)
+    torch.cuda.synchronize()
+    assert (full is not None) == want_full
+    assert torch.equal(pooled, want_pool)
+    if want_full:
+        assert torch.equal(full, want)
+
+
 @pytest.mark.parametrize("N,CA,CB,Cout,H,W,upA,upB,act", [
     (1, 512, 256, 256, 54, 96, 2, 1, 1),        # conv8_1(up(n7)) + conv3_3_short(n3)        (ColorVidNet.py:124-127)
     (1, 256, 128, 128, 108, 192, 2, 1, 1),      # conv9_1 + conv2_2_short
