@@ -55,6 +55,16 @@ def test_argument_validation_without_gpu():
     d2 = _lib.DvcConvDesc(1, 4, 27, 45, 8, 3, 2, 1, 1, 1, 1, 1, 0, 0.0, 0, -1, 0, 0, 0, 0)
     assert lib.dvc_conv2d_out_hw(ctypes.byref(d2), ctypes.byref(oh), ctypes.byref(ow)) == 0
     assert (oh.value, ow.value) == (14, 23)
+    # dvc_conv2d_winograd_pool: dilation 1 only, an output of at least one pooling window, a pooled destination
+    dp = _lib.DvcConvDesc(1, 64, 27, 48, 64, 3, 1, 2, 2, 0, 1, 1, 1, 0.0, 0, -1, 0, 0, 0, 0, 0)
+    rc = lib.dvc_conv2d_winograd_pool(ctypes.byref(dp), one, one, None, None, one, one, 0, None, 0, None)
+    assert rc != 0 and b"dilation 1" in lib.dvc_last_error()
+    dp = _lib.DvcConvDesc(1, 64, 1, 48, 64, 3, 1, 1, 1, 0, 1, 1, 1, 0.0, 0, -1, 0, 0, 0, 0, 0)
+    rc = lib.dvc_conv2d_winograd_pool(ctypes.byref(dp), one, one, None, None, one, one, 0, None, 0, None)
+    assert rc != 0 and b"pooling window" in lib.dvc_last_error()
+    dp = _lib.DvcConvDesc(1, 64, 27, 48, 64, 3, 1, 1, 1, 0, 1, 1, 1, 0.0, 0, -1, 0, 0, 0, 0, 0)
+    rc = lib.dvc_conv2d_winograd_pool(ctypes.byref(dp), one, one, None, None, one, None, 0, None, 0, None)
+    assert rc != 0 and b"null argument" in lib.dvc_last_error()
 
 
 def test_conv_geometry_matches_torch():
