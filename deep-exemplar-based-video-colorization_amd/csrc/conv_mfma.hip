@@ -504,7 +504,9 @@ static void wino_plan(const DvcConvDesc* d, int OH, int OW, bool have_workspace,
     }
     // dvc_debug_conv_variant(128 / 256): half the split / no split (fewer partial sums, longer workgroups, chip under-filled by
     // this launch alone) — the same probe asks whether the multi-stream driver prefers that
-    if ((g_conv_dbg & (128 | 256)) && d->split_k == 0 && best_m >= 0 && best_S > 1) {
+    // (8192: half the split only for launches that carry a batch — a stand-in for batch-aware planning, tools/bench_variant.py
+    // --front-batch 2)
+    if (((g_conv_dbg & (128 | 256)) || ((g_conv_dbg & 8192) && d->N >= 2)) && d->split_k == 0 && best_m >= 0 && best_S > 1) {
         const int kc = kWinoShapes[best_m].kc, nch = d->Cin / kc;
         int S2 = (g_conv_dbg & 256) ? 1 : best_S / 2;
         while (S2 > 1 && cdiv(nch, cdiv(nch, S2)) != S2) --S2;
