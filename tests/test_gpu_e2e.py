@@ -129,6 +129,35 @@ def test_free_running_clip_small_and_frame_propagate(frame_propagate):
         assert (other[0] - got[0]).abs().max().item() > 1e-3
 
 
+def test_long_free_running_clip_replayed_as_hipgraphs_48x80():
+    """32 free-running frames (test.py:68-96 runs whole clips; the recurrence feeds every prediction back) through the clip
+    driver with the per-frame launch sequences REPLAYED as hipGraphs (ClipColorizer(graph=True), look-ahead 2), against
+    oracle.colorize_clip: the literal 1e-3 on every frame, no growth along the clip, and bit-identical to the eager clip.
+    (All 32 frames have an oracle top-1/top-2 affinity gap >= 8e-6 at this size, checked once on the CPU.)"""
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    from oracle import dvc_oracle as O
+    H, W, T, NF = 48, 80, 1e-10, 32
+    _oracle_threads()
+    sd = _state_dicts()
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
+    frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W) for i in range(NF)]
+    cc = ClipColorizer(*_fresh_nets(sd), temperature=T, graph=True)
+    cc.set_exemplar(IB.cuda())
+    got = cc.clip([f.cuda() for f in frames], lookahead=2)
+    torch.cuda.synchronize()
+    eager = cc.clip([f.cuda() for f in frames], lookahead=2, graph=False)
+    for a, b in zip(got, eager):
+        assert torch.equal(a, b), "replayed clip != eager clip"
+    with torch.no_grad():
+        ref = O.colorize_clip(frames, IB, *sd, temperature=T)
+    errs = [(g.cpu() - r).abs().max().item() for g, r in zip(got, ref)]
+    report(f"e2e literal 48x80, {NF} free-running frames, hipGraph replay: gpu-vs-oracle max per frame "
+           f"first 8 {[f'{e:.1e}' for e in errs[:8]]} ... last 8 {[f'{e:.1e}' for e in errs[-8:]]}; max {max(errs):.2e}")
+    assert max(errs) <= NORTH_STAR_TOL and max(errs) <= 2.5e-4, errs
+    assert max(errs[-8:]) <= 4 * max(max(errs[:8]), 1e-5), errs         # no drift along the recurrence
+
+
 def test_config4_432x768_against_oracle():
     """BASELINE configs[3] (432x768, N = 20736 correlation positions) against ORACLE TENSORS, stage by stage on
     identical stage inputs and end to end: VGG taps, WarpNet trunk, theta/phi, similarity map, arg-max, warped
