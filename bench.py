@@ -10,6 +10,9 @@ prediction): VGG19(A) -> WarpNet(A) + fused correlation -> ColorVidNet on one sy
 already resident in HBM.  The K timed steps go through `ClipColorizer.clip` (front end of the next frames on side
 HIP streams, ColorVidNet recurrence on the main one; bit-identical to per-frame `frame_colorization` calls, which
 are timed right after and reported as `config.per_frame_api_frames_per_s`; `--lookahead 0` times those instead).
+The K-step clip is timed `config.repeats` times back to back (same frames, same recurrence start, each repeat bracketed by
+barrier + synchronize; enough repeats for >= 0.5 s of timed GPU work whatever K is): `ms_per_step` / `value` are the MEDIAN
+repeat, p10 / p90 are in `config` (">= 50 timed, median + p10/p90").
 N=1 runs BASELINE.json configs[1].  With N>1 each rank colourises its own contiguous chunk of K frames (weak
 scaling; the exemplar-side tensors are computed on rank 0 and broadcast once over RCCL/xGMI; no collective in
 the per-frame path).  `--gpus N` with N > 1 outside torch.distributed.run re-launches itself under it (one process
@@ -132,7 +135,7 @@ def _cpu_leg(sd, threads, n_warm, n_timed, budget_s):
 
 def cpu_baseline(sd):
     """the reference's path on this box's host cores, same synthetic clip, fp32, flush-denormal,
-    k = every usable hardware thread and k = 1, 5 timed frames each, median.  What is timed is the oracle — the
+    k = every usable hardware thread and k = 1, 2 warm-up + 5 timed frames each, median.  What is timed is the oracle — the
     op-for-op torch-CPU restatement that oracle/pin_reference.py shows bit-identical to the unmodified reference
     modules (`kind: "port"`; /root/reference does not exist on the GPU box).  ATen's CPU kernels stop scaling well
     below a 128-thread host, so a 32-thread leg is timed too and `value` is the FASTEST leg.  Every leg has a time
@@ -154,7 +157,8 @@ def cpu_baseline(sd):
         return best
 
     try:
-        for k, warm, timed, budget in sorted({(avail, 1, 5, 20.0), (min(avail, 32), 1, 5, 20.0), (1, 1, 5, 25.0)}):
+        # (2 warm-up + >= 5 timed frames per leg; the one-thread leg costs ~1.8 s per frame)
+        for k, warm, timed, budget in sorted({(avail, 2, 5, 20.0), (min(avail, 32), 2, 5, 20.0), (1, 2, 5, 30.0)}):
             if k > 32:
                 p_all, p_32 = probe(k), probe(32)
                 if p_all > 3.0 * p_32:
@@ -182,10 +186,33 @@ def cpu_baseline(sd):
     return {"value": legs[best]["frames_per_s"], "unit": "frames/s", "cores": best, "kind": "port",
             "sample": "216x384 frames of the same synthetic clip (exemplar seed 2, frames 1000..), oracle "
                       "frame_colorization recurrence = the reference op for op (exemplar side recomputed per frame as "
-                      "the reference does), torch CPU fp32, flush-denormal; 1 warm-up + 5 timed frames per leg, median; "
+                      "the reference does), torch CPU fp32, flush-denormal; 2 warm-up + 5 timed frames per leg, median; "
                       f"`value` is the fastest leg ({best} threads)",
             "host": {"threads_usable": avail, "threads_usable_from": how, "cpu": cpu_model},
             "by_threads": {str(k): v for k, v in sorted(legs.items())}}
+
+
+def executed_matrix_flops(cc, frame, last):
+    """(executed, direct-equivalent) matrix FLOPs of ONE frame as the HIP path runs it: every convolution launch of a per-frame
+    call is recorded (ops.conv_record) and priced by the engine that ran it — direct implicit GEMM 2 k^2 Cin Cout OH OW, Winograd
+    F(2x2,3x3) 2 * 16 Cin Cout per 2x2 output tile (2.25x fewer) — plus the fused correlation's 13.92 GFLOP (CORR_FLOPS)."""
+    from dvc_amd import ops
+    ops.conv_record = rec = []
+    try:
+        cc.frame(frame, last, graph=False)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv_record = None
+    executed = direct = 0.0
+    for r in rec:
+        OH, OW = ops.conv_out_hw(r["H"], r["W"], r["ksize"], r["stride"], r["dil"], r["pad"], r["in_up"], r["in_sub"])
+        d = 2.0 * r["ksize"] ** 2 * r["Cin"] * r["Cout"] * OH * OW * r["N"]
+        direct += d
+        if str(r.get("algo", "")).startswith("winograd"):
+            executed += 2.0 * 16 * r["Cin"] * r["Cout"] * ((OH + 1) // 2) * ((OW + 1) // 2) * r["N"]
+        else:
+            executed += d
+    return executed + CORR_FLOPS, direct + CORR_FLOPS, len(rec)
 
 
 def relaunch_under_torchrun(n):
@@ -222,6 +249,12 @@ def main():
                     help="issue every kernel launch from Python instead of replaying the captured per-frame launch sequences "
                          "(hipGraph, dvc_amd/graph.py); results are bit-identical either way")
     ap.add_argument("--no-autotune", action="store_true", help="use the static tile cost model instead of first-use timing")
+    ap.add_argument("--min-timed-s", type=float, default=0.5,
+                    help="the K-step clip is repeated until at least this much GPU work has been timed (>= 3 repeats); the line "
+                         "reports the median repeat with p10 / p90")
+    ap.add_argument("--refs", type=int, default=4,
+                    help="R of the multi-reference leg (config.multi_reference: the same clip against R exemplars in one pass, "
+                         "test.py:169-181); 0 skips the leg")
     ap.add_argument("--corr", choices=["fp32", "bf16"], default="fp32",
                     help="bf16 = BASELINE configs[4]: bf16 MFMA candidate filter + exact fp32 re-scoring")
     ap.add_argument("--no-exemplar-cache", action="store_true",
@@ -331,78 +364,92 @@ def main():
             torch.cuda.synchronize()
     for i in range(Wm):
         last = step(i, last)
+    # launch mode of the timed region: FIXED (r04) — look-ahead front ends replayed as hipGraphs, ColorVidNet chain launched
+    # kernel by kernel (ClipColorizer.graph_parts); the other mode (every launch from Python) is timed after the timed region
+    # and reported next to it.  (r03 chose the faster of the two on a warm-up trial: a best-of selection.)
     clip_graph = use_graph
     if args.lookahead > 0:
         # second untimed pass over the warm-up frames through the clip driver: the side streams' memory
         # pools (and nothing else) are still cold after the per-frame pass above
-        cc.clip(frames[:Wm], lookahead=args.lookahead, front_batch=args.front_batch)
-        if use_graph and Wm >= 2:
-            # Replayed front ends are worth +2 % here, but how HIP maps streams onto hardware queues decides whether replayed
-            # graphs overlap with the recurrence stream at all (profiles/r03_graph_overlap_probe.txt, r03_cu_mask_probe.txt:
-            # 333 instead of 406 frames/s in a process that had used three more streams).  Both ways of issuing the SAME
-            # launches are timed on the warm-up frames (untimed region) and the faster one is used for the K timed steps;
-            # the line says which.  Results are bit-identical either way (asserted below).
-            def trial(g):
-                cc.clip(frames[:Wm], lookahead=args.lookahead, graph=g)
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for _ in range(2):
-                    cc.clip(frames[:Wm], lookahead=args.lookahead, graph=g)
-                torch.cuda.synchronize()
-                return time.perf_counter() - t
-            t_graph, t_eager = trial(True), trial(False)
-            clip_graph = t_graph <= t_eager * 1.01
-            log(f"[bench] clip driver on the warm-up frames: front ends replayed {t_graph * 1e3:.2f} ms, every launch from Python "
-                f"{t_eager * 1e3:.2f} ms -> timing with {'replayed front ends' if clip_graph else 'launches from Python'}")
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if args.lookahead > 0:
-        # the clip driver: front end (VGG19 + WarpNet + correlation) of frames t+1.. on side HIP streams while
-        # this stream runs the ColorVidNet recurrence; bit-identical to the per-frame loop below
-        cc.clip(frames[Wm:Wm + K], last=last, lookahead=args.lookahead, front_batch=args.front_batch, graph=clip_graph)
-        last_timed = cc.last_lab
-    else:
-        last_timed = last
+        cc.clip(frames[:Wm], lookahead=args.lookahead, front_batch=args.front_batch, graph=clip_graph)
+
+    def timed_clip():
+        """Exactly K steps of the recurrence from the state after the warm-up frames; returns the final [L, ab]."""
+        if args.lookahead > 0:
+            # the clip driver: front end (VGG19 + WarpNet + correlation) of frames t+1.. on side HIP streams while
+            # this stream runs the ColorVidNet recurrence; bit-identical to the per-frame loop below
+            cc.clip(frames[Wm:Wm + K], last=last, lookahead=args.lookahead, front_batch=args.front_batch, graph=clip_graph)
+            return cc.last_lab
+        lt = last
         for i in range(Wm, Wm + K):
-            last_timed = step(i, last_timed)
-    torch.cuda.synchronize()
+            lt = step(i, lt)
+        return lt
+
+    def bracket():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # one untimed pass of the K steps: sizes the number of repeats (the same on every rank) and is the last piece of warm-up
+    bracket()
+    t0 = time.perf_counter()
+    timed_clip()
+    bracket()
+    est = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        dist.all_reduce(est, op=dist.ReduceOp.MAX)
+    repeats = int(min(400, max(3, -(-args.min_timed_s // max(est.item(), 1e-6)))))
+    rep_s = []
+    for _ in range(repeats):
+        bracket()
+        t0 = time.perf_counter()
+        last_timed = timed_clip()
+        bracket()
+        rep_s.append(time.perf_counter() - t0)
+    def median_s(fn, n):
+        """Median wall time of `fn()` over n runs (each synchronised), and its last result."""
+        ts, res = [], None
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        return sorted(ts)[len(ts) // 2], res
+
+    side_reps = max(1, min(repeats, 5))
     # the same K frames through the reference's per-frame API (frame_colorization called frame by frame, no
     # look-ahead possible): reported next to `value`, and checked to give the same predictions
     seq_fps = None
     if args.lookahead > 0 and rank == 0:
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        last_seq = last
-        for i in range(Wm, Wm + K):
-            last_seq = step(i, last_seq)
-        torch.cuda.synchronize()
-        seq_fps = K / (time.perf_counter() - t1)
+        def per_frame_loop():
+            lt = last
+            for i in range(Wm, Wm + K):
+                lt = step(i, lt)
+            return lt
+        t_seq, last_seq = median_s(per_frame_loop, side_reps)
+        seq_fps = K / t_seq
         assert torch.equal(last_seq, last_timed), "pipelined clip driver != per-frame loop"
     # ... and, when the timed region replayed captured launch sequences, the same K frames with every launch issued from
     # Python (what r01/r02 timed): reported next to `value`, and required to give the same predictions bit for bit
-    eager_fps = other_fps = None
+    eager_fps = None
     if use_graph and args.lookahead > 0 and rank == 0:
-        cc.clip(frames[:Wm], lookahead=args.lookahead, graph=not clip_graph)          # (side-stream allocator pools)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        cc.clip(frames[Wm:Wm + K], last=last, lookahead=args.lookahead, graph=not clip_graph)
-        torch.cuda.synchronize()
-        eager_fps = K / (time.perf_counter() - t1)
-        assert torch.equal(cc.last_lab, last_timed), "hipGraph replay != eager launches"
-        if not clip_graph:
-            eager_fps, other_fps = None, eager_fps      # the timed region WAS the eager one: this leg timed the replayed front ends
+        cc.clip(frames[:Wm], lookahead=args.lookahead, graph=False)          # (side-stream allocator pools)
+
+        def eager_clip():
+            cc.clip(frames[Wm:Wm + K], last=last, lookahead=args.lookahead, graph=False)
+            return cc.last_lab
+        t_eager, last_eager = median_s(eager_clip, side_reps)
+        eager_fps = K / t_eager
+        assert torch.equal(last_eager, last_timed), "hipGraph replay != eager launches"
     last = last_timed
+    t = torch.tensor(rep_s, device=device, dtype=torch.float64)
     if use_dist:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)        # per repeat: the slowest rank
+    rep_sorted = sorted(t.tolist())
+    pick = lambda q: rep_sorted[min(len(rep_sorted) - 1, max(0, int(round(q * (len(rep_sorted) - 1)))))]   # noqa: E731
+    elapsed = pick(0.5)                                 # the MEDIAN repeat of exactly K steps
     assert torch.isfinite(last).all(), "non-finite output"
     fps = n_gpus * K / elapsed
 
@@ -436,6 +483,8 @@ def main():
         t_corr = e0.elapsed_time(e1) * 1e-3 / reps      # fused kernel + its (tiny) merge kernel
         achieved = CORR_FLOPS / t_corr / 1e12
         traffic, traffic_src = corr_traffic() if (H, W) == (216, 384) else (None, {"kind": "not measured at this size"})
+        exec_flops, direct_flops, n_convs = executed_matrix_flops(cc, frames[Wm], torch.zeros_like(frames[Wm]))
+        exec_tflops = exec_flops * fps / n_gpus / 1e12
         roof = {"kernel": "corr_fwd_kernel (+corr_merge_kernel)", "bound": "mfma",
                 "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
@@ -446,11 +495,17 @@ def main():
                              "frac": round(CORR_BYTES / t_corr / 1e9 / PEAK_HBM_GBS, 5),
                              "note": "fused kernel never materialises the PxP affinity; compulsory bytes "
                                      "10.76 MB/frame make it MFMA-bound, not HBM-bound (SURVEY.md 8d)"},
-                "whole_path": {"achieved": round(PATH_FLOPS * fps / n_gpus / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(PATH_FLOPS * fps / n_gpus / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                               "flop_count": "algorithmic FLOPs of the path with direct convolutions (348.4 GFLOP per 216x384 "
-                                             "frame, SURVEY.md 8d) x frames/s: an EFFECTIVE rate - the Winograd layers execute "
-                                             "2.25x fewer multiplications, so it may exceed the matrix peak"}}
+                "whole_path": {"executed": {"achieved": round(exec_tflops, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": round(exec_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                                            "gflop_per_frame": round(exec_flops / 1e9, 2),
+                                            "flop_count": f"matrix FLOPs the kernels EXECUTE per frame ({n_convs} convolution launches "
+                                                          "recorded from a per-frame call and priced by the engine that ran them: "
+                                                          "Winograd F(2x2,3x3) 16 instead of 36 multiplications per 2x2 tile and channel "
+                                                          "pair; + 13.92 GFLOP correlation) x frames/s / fp32 MFMA peak"},
+                               "effective_tflops": round(PATH_FLOPS * fps / n_gpus / 1e12, 3),
+                               "effective_note": "348.4 GFLOP per 216x384 frame (SURVEY.md 8d: algorithmic FLOPs with DIRECT "
+                                                 "convolutions; counted here: %.1f) x frames/s - NOT a roofline fraction: the "
+                                                 "Winograd layers execute 2.25x fewer multiplications" % (direct_flops / 1e9)}}
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
@@ -478,19 +533,21 @@ def main():
                        "conv_tile_choice": "static cost model" if args.no_autotune else
                        "autotuned on first use during warm-up (cf. cudnn.benchmark=True, test.py:140)",
                        "frames_per_gpu": K, "parallelism": f"frame-chunks x{n_gpus}",
+                       "repeats": repeats, "ms_per_step_p10": round(pick(0.1) / K * 1e3, 4),
+                       "ms_per_step_p90": round(pick(0.9) / K * 1e3, 4),
+                       "timed_gpu_seconds": round(sum(rep_sorted), 3),
+                       "timing": f"the K = {K} step clip timed {repeats} times back to back from the same recurrence state, every "
+                                 "repeat bracketed by barrier + synchronize; ms_per_step / value = the median repeat",
                        "clip_driver": "per-frame calls, one stream" if args.lookahead <= 0 else
                        f"ClipColorizer.clip: front end of the next {args.lookahead} frames on side HIP streams, " +
                        (f"{args.front_batch} frames per set of front-end launches (planned per image), " if args.front_batch > 1 else "") +
                        "ColorVidNet recurrence on the main stream (bit-identical to per-frame calls)",
                        "launches": ("look-ahead front ends replayed as hipGraphs (one captured sequence per side stream), ColorVidNet "
                                     "chain launched kernel by kernel; per-frame API: both sequences replayed; bit-identical to "
-                                    "eager launches" if clip_graph else
-                                    "clip driver: every kernel launched from Python (faster than replayed front ends on this box "
-                                    "in the untimed trial); per-frame API: both sequences replayed as hipGraphs") if use_graph else
+                                    "eager launches (fixed mode, no warm-up trial)") if use_graph else
                                    (graph_note or "every kernel launched from Python"),
                        "per_frame_api_frames_per_s": None if seq_fps is None else round(seq_fps, 3),
-                       "eager_launch_clip_driver_frames_per_s": None if eager_fps is None else round(eager_fps, 3),
-                       "replayed_front_end_clip_driver_frames_per_s": None if other_fps is None else round(other_fps, 3)},
+                       "eager_launch_clip_driver_frames_per_s": None if eager_fps is None else round(eager_fps, 3)},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

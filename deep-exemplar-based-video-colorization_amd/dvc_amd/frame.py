@@ -113,7 +113,8 @@ class ClipColorizer:
         self._side_streams = []
         self._main_stream = None
         self._tail_stream = None
-        self._graphs = {}            # (kind, shape, slot) -> _FrontSlot / _ColorChain
+        self._graphs = {}            # (kind, shape, slot, ...) -> _FrontSlot / _ColorChain
+        self._weights_fp = None      # (data_ptr, version) of every parameter when the weights were last packed
 
     def prepare(self):
         """Pack all weights of the three networks on the current stream (idempotent, cheap when warm)."""
@@ -121,6 +122,16 @@ class ClipColorizer:
             prep = getattr(net, "prepare", None)
             if prep is not None:
                 prep()
+
+    def _sync_weights(self):
+        """Make the packed weights (and with them `nets.pack_epoch()`, which marks captured sequences stale) follow the
+        parameters: an in-place `load_state_dict` or a `.cuda()` is only noticed by `_PackCache.get`, i.e. by an eager
+        forward or `prepare()` — a replayed graph calls neither.  The fingerprint costs ~140 attribute reads; `prepare()`
+        runs only when it moved."""
+        fp = tuple((p.data_ptr(), p._version) for net in (self.vgg, self.warp, self.col) for p in net.parameters())
+        if fp != self._weights_fp:
+            self.prepare()
+            self._weights_fp = fp
 
     def set_exemplar(self, IB_lab):
         """test.py:61-66: Lab -> RGB -> VGG features of the reference image."""
@@ -185,8 +196,16 @@ class ClipColorizer:
     def _captured(self, kind, shape, device, slot, stream):
         # (everything a captured launch bakes in besides addresses: the frame geometry, the temperature — a kernel argument and
         # the choice of the correlation's instantiation — and the correlation precision)
-        key = (kind, tuple(shape), slot, float(self.temperature), getattr(self.warp, "corr_precision", "fp32"))
+        key = (kind, tuple(shape), slot, float(self.temperature), getattr(self.warp, "corr_precision", "fp32"), device.index)
         g = self._graphs.get(key)
+        if g is None:
+            # a superseded sequence keeps its activation arena alive: at most two (geometry, temperature, precision)
+            # variants stay per (kind, slot) — enough to alternate between two clip sizes without re-capturing
+            same = [k for k in self._graphs if k[0] == kind and k[2] == slot and k[5] == device.index]
+            if len(same) >= 2:
+                torch.cuda.synchronize()
+                for k in same[:-1]:
+                    del self._graphs[k]
         if g is None or g.seq.stale():
             if self.ex_cache is None:
                 raise RuntimeError("ClipColorizer(graph=True) needs the exemplar cache (cache_exemplar=True + set_exemplar)")
@@ -229,6 +248,7 @@ class ClipColorizer:
     def _frame_graph(self, IA_lab, prev):
         """The per-frame call as two graph replays on the CURRENT stream (no look-ahead is possible through this API: the
         next frame is not known).  The outputs are cloned out of the graphs' arenas (the next call overwrites them)."""
+        self._sync_weights()        # (a replay never reaches nets._PackCache: reloaded weights are noticed here)
         front = self._captured("front", IA_lab.shape, IA_lab.device, "seq", self._capture_stream())
         chain = self._captured("color", IA_lab.shape, IA_lab.device, 0, self._capture_stream())
         front.IA_in.copy_(IA_lab)
@@ -263,6 +283,9 @@ class ClipColorizer:
         if not frames_lab:
             return []
         use_graph = self.graph if graph is None else bool(graph)
+        if use_graph and int(front_batch) > 1:
+            raise ValueError("ClipColorizer.clip: front_batch > 1 is not available with graph=True (a captured front end "
+                             "holds one frame per slot); pass graph=False or front_batch=1")
         if last is None:
             last = self.IB_lab if frame_propagate else torch.zeros_like(frames_lab[0])
         last = last.detach().contiguous().float()
@@ -346,6 +369,7 @@ class ClipColorizer:
         the slot's next replay overwrites them; `cin` and `ab` are reused in stream order on the recurrence stream."""
         T, L = len(frames_lab), len(side)
         shape, dev = frames_lab[0].shape, frames_lab[0].device
+        self._sync_weights()
         for s in side + [cur]:
             s.wait_stream(caller)
         eager_front = self.graph_parts == "color"       # (experiments: tools/graph_overlap_probe.py)

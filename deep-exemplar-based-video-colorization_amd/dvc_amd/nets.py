@@ -436,6 +436,9 @@ class ColorVidNet(nn.Module):
             return False
         (N, CA, HA, WA), (_, CB, HB, WB) = shapeA, shapeB
         upA = 2 if cA["pre"] == "up" else 1
+        # (dvc_conv2d_winograd_dual forces the 64-channel x 32-tile workgroup shape and stages 8-channel chunks of each input)
+        if cA["cout"] % 64 or cB["cout"] != cA["cout"] or CA % 8 or CB % 8:
+            return False
         return (ops.winograd_selected(N, CA, HA, WA, cA["cout"], dil=cA["dil"], pad=cA["dil"], in_up=upA)
                 and ops.winograd_selected(N, CB, HB, WB, cB["cout"], dil=cB["dil"], pad=cB["dil"]))
 

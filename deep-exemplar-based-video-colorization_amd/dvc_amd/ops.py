@@ -597,7 +597,9 @@ def channel_l2norm_multi(xs, eps=EPS64):
     for i, x in enumerate(xs):
         _need(x, f"x[{i}]")
     N = xs[0].shape[0]
-    if len(xs) > 8 or any(x.shape[0] != N or (x.shape[2] * x.shape[3]) % 4 for x in xs):
+    # (the one-launch kernel moves float4 pieces: every plane size a multiple of 4 and every base pointer 16-byte aligned —
+    # an offset or sliced feature tensor takes the per-map scalar kernel, as it did before the multi entry existed)
+    if len(xs) > 8 or any(x.shape[0] != N or (x.shape[2] * x.shape[3]) % 4 or x.data_ptr() % 16 for x in xs):
         return [channel_l2norm(x, eps) for x in xs]
     ys = [torch.empty_like(x) for x in xs]
     n = len(xs)
@@ -666,6 +668,11 @@ def pack_color_input(IA_lab, warped_lab, sim, IA_last_lab=None, *, last_l=None, 
         ll, ll_bs = _plane(last_l, 0, "last_l")
         la, la_bs = _plane(last_ab, 0, "last_ab")
         assert last_ab.shape[1] == 2
+    if out is not None:
+        _need(out, "out")
+        if tuple(out.shape) != (N, 7, H, W) or out.device != IA_lab.device:
+            raise RuntimeError(f"dvc_amd: pack_color_input: `out` must be a contiguous float32 [{N}, 7, {H}, {W}] tensor on "
+                               f"{IA_lab.device} (got {tuple(out.shape)} on {out.device})")
     y = torch.empty((N, 7, H, W), device=IA_lab.device, dtype=torch.float32) if out is None else out
     _lib.check(lib.dvc_pack_color_input(ia, ia_bs, _p(warped_lab), _p(sim), ll, ll_bs, la, la_bs, N, H * W, _p(y),
                                         _stream()), "dvc_pack_color_input")

@@ -269,9 +269,11 @@ def _run_clip(nets, H, W, nf, T, cache):
     return outs, warped
 
 
+@pytest.mark.parametrize("conv_algo", ["auto", "direct"], indirect=True)
 @pytest.mark.parametrize("name", ["small_48x80_T1e-10", "small_40x64_T0.01", "full_216x384_T1e-10"])
-def test_frame_colorization_vs_reference_golden(nets, golden_dir, name):
-    """End-to-end vs outputs recorded from the UNMODIFIED reference (oracle/pin_reference.py).
+def test_frame_colorization_vs_reference_golden(nets, weights, golden_dir, name, conv_algo):
+    """End-to-end vs outputs recorded from the UNMODIFIED reference (oracle/pin_reference.py), under both convolution
+    engines.
 
     Every frame is compared on IDENTICAL inputs: frame i's `IA_last_lab` is built from the golden
     prediction of frame i-1 (with random weights ColorVidNet amplifies a 1e-3 difference in IA_last
@@ -279,16 +281,29 @@ def test_frame_colorization_vs_reference_golden(nets, golden_dir, name):
     report line of the fp64 test — so a free-running comparison measures chaos, not the kernels).
     The golden is the reference's fp32 CPU run, itself 3e-3..6e-3 max-abs from the fp64 truth on ab,
     so this test pins the DISCRETE part exactly (which exemplar position every pixel picked; the
-    similarity map) and bounds the continuous part at that noise level."""
+    similarity map) and bounds the continuous part at that noise level — ON EVERY FRAME (r04; it used to be "at least
+    one clean frame"):
+      * frames whose smallest recorded top-1/top-2 gap is >= 2e-6 (both frames of small_48x80, frame 0 of full_216x384:
+        2.6e-5, 3.9e-5, 3.0e-6) must pick the reference's exemplar position on EVERY row;
+      * on the other frames (full_216x384 frame 1: a row with gap 6.0e-7, below fp32 resolution of a 256-term dot product) a
+        row may pick another position only if its recorded gap is < 1e-5, and `ab` is then compared with the reference
+        arithmetic evaluated WITH THAT TIE-BREAK: the oracle's ColorVidNet (bit-identical to the reference module,
+        oracle/pin_reference.py) on the golden warped colours / similarity / previous frame with the flipped rows' 4x4
+        blocks carrying the colour the HIP path chose.  Without a flip that evaluation IS the golden `ab`;
+      * the statistics every frame must meet: mean < 2e-3, p99 < 1e-2, and max below WORST_CASE_FACTOR x 6.4e-3 (the
+        reference's own fp32-vs-fp64 worst case on this network, test_colorvidnet) — i.e. 9.6e-3 for the direct engine
+        and 1.6e-2 for Winograd: the factor the less accurate engine costs is asserted, not just printed."""
+    import torch.nn.functional as F
     from dvc_amd import synth
     from dvc_amd.frame import VGG_OUT, frame_colorization
     from dvc_amd import ops
+    from oracle import dvc_oracle as O
     vgg, warp, col = nets
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     H, W, nf, T = int(g["H"]), int(g["W"]), int(g["n_frames"]), float(g["temperature"])
+    h, w = H // 4, W // 4
     IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).cuda()
     fB = vgg(ops.lab2rgb(IB, l_offset=50.0), VGG_OUT)
-    clean_frames = 0
     for i in range(nf):
         fr = synth.synth_lab(synth.FRAME_SEED0 + i, H, W).cuda()
         if i == 0:
@@ -297,31 +312,51 @@ def test_frame_colorization_vs_reference_golden(nets, golden_dir, name):
             prev = synth.synth_lab(synth.FRAME_SEED0 + i - 1, H, W)
             last = torch.cat((prev[:, 0:1], torch.from_numpy(g["ab"][i - 1])[None]), 1).cuda()
         ab, nl, _ = frame_colorization(fr, IB, last, fB, vgg, warp, col, joint_training=False, temperature=T)
-        d = np.abs(ab[0].cpu().numpy() - g["ab"][i])
-        wl = np.abs(nl[0, :, ::4, ::4].cpu().numpy() - g["warped_lab_small"][i])
-        safe = (g["top2gap"][i] > 1e-4).reshape(g["sim"][i].shape)
+        nl_small = nl[0, :, ::4, ::4].cpu()
+        wl = np.abs(nl_small.numpy() - g["warped_lab_small"][i])
+        gap = g["top2gap"][i].reshape(h, w)
         flips = (wl.max(0) > 1e-3)
-        report(f"e2e golden {name} frame{i}: ab max={d.max():.2e} mean={d.mean():.2e} p99={np.quantile(d, 0.99):.2e} "
-               f"warped max={wl.max():.2e} flipped_rows={int(flips.sum())} (unsafe rows {int((~safe).sum())})")
         if T < 1e-6:
-            assert not (flips & safe).any(), (name, i)      # a different exemplar pixel only on near-ties
-            assert wl[:, safe].max() < 1e-4
-            if not flips.any():
-                clean_frames += 1
-                assert d.mean() < 2e-3 and np.quantile(d, 0.99) < 1e-2, (name, i)
+            assert not (flips & (gap >= 1e-5)).any(), (name, i)     # a different exemplar pixel only on near-ties
+            if gap.min() >= 2e-6:
+                assert not flips.any(), (name, i, "this frame has no row below fp32 resolution: every row must agree")
+            assert wl[:, ~flips].max() < 1e-4
+            want = g["ab"][i]
+            if flips.any():
+                y_alt = torch.from_numpy(g["warped_lab_small"][i]).clone()
+                fm = torch.from_numpy(flips)
+                y_alt[:, fm] = nl_small[:, fm]
+                nthreads = torch.get_num_threads()
+                torch.set_num_threads(int(g["num_threads"]))        # the thread count the golden was recorded with
+                try:
+                    with torch.no_grad():
+                        cin = torch.cat((fr.cpu()[:, 0:1], F.interpolate(y_alt[None], scale_factor=4, mode="nearest")[:, 1:3],
+                                         F.interpolate(torch.from_numpy(g["sim"][i])[None, None], scale_factor=4, mode="nearest"),
+                                         last.cpu()), dim=1)
+                        want = O.colorvidnet_forward(weights[2], cin)[0].numpy()
+                finally:
+                    torch.set_num_threads(nthreads)
+            d = np.abs(ab[0].cpu().numpy() - want)
+            report(f"e2e golden {name} conv={conv_algo} frame{i}: ab max={d.max():.2e} mean={d.mean():.2e} p99={np.quantile(d, 0.99):.2e} "
+                   f"warped max on agreeing rows={wl[:, ~flips].max():.2e} flipped_rows={int(flips.sum())} (their gaps "
+                   f"{gap[flips].tolist()}; rows with gap<1e-5: {int((gap < 1e-5).sum())}; tie-break-matched reference: {bool(flips.any())})")
+            assert d.mean() < 2e-3 and np.quantile(d, 0.99) < 1e-2, (name, i)
+            assert d.max() < WORST_CASE_FACTOR[conv_algo] * 6.4e-3, (name, i, d.max())
         else:   # soft temperature: d(y)/d(f) = |B_lab|/T ~ 1e4 and fp32 affinities differ by ~1e-6
-            clean_frames += 1
+            d = np.abs(ab[0].cpu().numpy() - g["ab"][i])
+            report(f"e2e golden {name} conv={conv_algo} frame{i}: ab max={d.max():.2e} mean={d.mean():.2e} warped max={wl.max():.2e}")
             assert wl.max() < 5e-2 and d.mean() < 0.1, (name, i)
-    assert clean_frames >= 1
 
 
-@pytest.mark.parametrize("conv_algo", ["auto", "direct"], indirect=True)
 @pytest.mark.parametrize("H,W,T", [(48, 80, 1e-10), (40, 64, 0.01), (216, 384, 1e-10)])
-def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights, H, W, T, conv_algo):
+def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights, H, W, T):
     """The honest form of the "ab within 1e-3" claim with the chaotic random weights (SURVEY.md §7 hard part 1): GPU-fp32
-    vs the fp64 truth, next to the reference-equivalent CPU-fp32 vs the same truth.  Pass = within 1e-3, or no further
-    from the truth than 1.5x the CPU fp32 run in the mean and WORST_CASE_FACTOR x in the 99.9th percentile."""
-    from dvc_amd import synth
+    vs the fp64 truth, next to the reference-equivalent CPU-fp32 vs the same truth, under BOTH convolution engines in one
+    test.  Pass = within 1e-3, or no further from the truth than 1.5x the CPU fp32 run in the mean and WORST_CASE_FACTOR x in
+    the 99.9th percentile.  r04: the price of the Winograd engine is asserted as a ratio between the two engines' errors
+    against the same truth — worst case <= 2.5x, mean <= 1.6x the direct engine's (measured r03 at 216x384: 1.10e-2 vs
+    4.97e-3 max, 8.0e-4 vs 6.0e-4 mean) — and the direct engine must be at or below the CPU fp32 run's worst case."""
+    from dvc_amd import ops, synth
     from oracle import dvc_oracle as O
     sd32 = weights
     sd64 = tuple(O.to_dtype(s, torch.float64) for s in weights)
@@ -333,28 +368,43 @@ def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights, H, W, T, conv_
         ab32, nl32, _ = O.frame_colorization(fr, IB, last, fB32, *sd32, temperature=T)
         fB64 = O.exemplar_features(IB.double(), sd64[0])
         ab64, nl64, _ = O.frame_colorization(fr.double(), IB.double(), last.double(), fB64, *sd64, temperature=T)
-    outs, warped = _run_clip(nets, H, W, 1, T, cache=True)
-    e_gpu = (outs[0].double().cpu() - ab64).abs()
     e_cpu = (ab32.double() - ab64).abs()
-    w_gpu = (warped[0].double().cpu() - nl64).abs()
     w_cpu = (nl32.double() - nl64).abs()
     q = lambda t: np.quantile(t.numpy(), 0.999)
-    report(f"e2e vs fp64 {H}x{W} T={T} conv={conv_algo}: GPU ab max={e_gpu.max():.2e} q999={q(e_gpu):.2e} mean={e_gpu.mean():.2e} | "
-           f"CPU32 ab max={e_cpu.max():.2e} q999={q(e_cpu):.2e} mean={e_cpu.mean():.2e} | "
-           f"warped GPU max={w_gpu.max():.2e} CPU32 max={w_cpu.max():.2e}")
-    assert e_gpu.mean().item() < max(1e-3, 1.5 * e_cpu.mean().item())
-    assert q(e_gpu) < max(1e-3, WORST_CASE_FACTOR[conv_algo] * q(e_cpu))
-    assert w_gpu.max().item() < max(1e-3, 2.0 * w_cpu.max().item())
-    if H <= 64:
-        # report only: how a FREE-RUNNING second frame (IA_last = own previous prediction) diverges
-        fr1 = synth.synth_lab(synth.FRAME_SEED0 + 1, H, W)
-        with torch.no_grad():
-            a32, _, _ = O.frame_colorization(fr1, IB, torch.cat((fr[:, 0:1], ab32), 1), fB32, *sd32, temperature=T)
-            a64, _, _ = O.frame_colorization(fr1.double(), IB.double(), torch.cat((fr[:, 0:1].double(), ab64), 1),
-                                             fB64, *sd64, temperature=T)
-        o2, _ = _run_clip(nets, H, W, 2, T, cache=True)
-        report(f"free-running frame1 {H}x{W} T={T}: GPU-vs-fp64 mean={(o2[1].double().cpu() - a64).abs().mean():.2e} "
-               f"| CPU32-vs-fp64 mean={(a32.double() - a64).abs().mean():.2e}")
+    errs = {}
+    old = ops.conv_algo()
+    try:
+        for algo in ("auto", "direct"):
+            ops.set_conv_algo(algo)
+            outs, warped = _run_clip(nets, H, W, 1, T, cache=True)
+            e_gpu = (outs[0].double().cpu() - ab64).abs()
+            w_gpu = (warped[0].double().cpu() - nl64).abs()
+            errs[algo] = e_gpu
+            report(f"e2e vs fp64 {H}x{W} T={T} conv={algo}: GPU ab max={e_gpu.max():.2e} q999={q(e_gpu):.2e} mean={e_gpu.mean():.2e} | "
+                   f"CPU32 ab max={e_cpu.max():.2e} q999={q(e_cpu):.2e} mean={e_cpu.mean():.2e} | "
+                   f"warped GPU max={w_gpu.max():.2e} CPU32 max={w_cpu.max():.2e}")
+            assert e_gpu.mean().item() < max(1e-3, 1.5 * e_cpu.mean().item())
+            assert q(e_gpu) < max(1e-3, WORST_CASE_FACTOR[algo] * q(e_cpu))
+            assert w_gpu.max().item() < max(1e-3, 2.0 * w_cpu.max().item())
+            if H <= 64 and algo == "auto":
+                # report only: how a FREE-RUNNING second frame (IA_last = own previous prediction) diverges
+                fr1 = synth.synth_lab(synth.FRAME_SEED0 + 1, H, W)
+                with torch.no_grad():
+                    a32, _, _ = O.frame_colorization(fr1, IB, torch.cat((fr[:, 0:1], ab32), 1), fB32, *sd32, temperature=T)
+                    a64, _, _ = O.frame_colorization(fr1.double(), IB.double(), torch.cat((fr[:, 0:1].double(), ab64), 1),
+                                                     fB64, *sd64, temperature=T)
+                o2, _ = _run_clip(nets, H, W, 2, T, cache=True)
+                report(f"free-running frame1 {H}x{W} T={T}: GPU-vs-fp64 mean={(o2[1].double().cpu() - a64).abs().mean():.2e} "
+                       f"| CPU32-vs-fp64 mean={(a32.double() - a64).abs().mean():.2e}")
+    finally:
+        ops.set_conv_algo(old)
+    r_max = errs["auto"].max().item() / errs["direct"].max().item()
+    r_mean = errs["auto"].mean().item() / errs["direct"].mean().item()
+    report(f"e2e vs fp64 {H}x{W} T={T}: Winograd / direct error ratio max {r_max:.2f} mean {r_mean:.2f}; direct / CPU32 max "
+           f"{errs['direct'].max().item() / e_cpu.max().item():.2f}")
+    if T < 1e-6:        # (at the soft temperature the correlation's 1/T dominates both engines' errors)
+        assert r_max <= 2.5 and r_mean <= 1.6, (r_max, r_mean)
+        assert errs["direct"].max().item() <= 1.2 * e_cpu.max().item()
 
 
 def test_clip_recurrence_cached_equals_uncached_and_deterministic(nets):
@@ -655,6 +705,46 @@ def test_graph_replay_equals_eager():
         bad = ClipColorizer(*nets, temperature=1e-10, cache_exemplar=False, graph=True)
         bad.set_exemplar(IB)
         bad.clip(frames[:2], lookahead=0)
+
+
+def test_graph_replay_notices_reloaded_weights_without_an_eager_call():
+    """Advisor (r03): a replayed sequence never reaches nets._PackCache, so an in-place `load_state_dict` followed DIRECTLY by
+    a graph-mode call — no eager forward, no prepare() in between — used to replay the graphs that read the OLD packed weights.
+    ClipColorizer._sync_weights fingerprints the parameters before every replayed call: the per-frame call, the sequential
+    clip and the pipelined clip must all see the new weights."""
+    import contextlib
+    import io
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    from models.ColorVidNet import ColorVidNet
+    from models.NonlocalNet import VGG19_pytorch, WarpNet
+    dev = torch.device("cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        nets = (VGG19_pytorch(), WarpNet(1), ColorVidNet(7))
+    for m, sd in zip(nets, (synth.vgg19_state_dict(0), synth.warpnet_state_dict(0), synth.colorvidnet_state_dict(0))):
+        m.load_state_dict(sd)
+        m.eval().to(dev)
+    H, W = 48, 80
+    frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W).to(dev) for i in range(3)]
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).to(dev)
+    zero = torch.zeros_like(frames[0])
+    cc = ClipColorizer(*nets, temperature=1e-10, graph=True)
+    cc.set_exemplar(IB)
+    ab0, _ = cc.frame(frames[0], zero)                     # captures both sequences
+    for step, seed in enumerate((5, 6, 7)):
+        nets[2].load_state_dict(synth.colorvidnet_state_dict(seed))     # in place: same parameter objects, new versions
+        if step == 0:
+            got = cc.frame(frames[0], zero)[0]
+        elif step == 1:
+            got = cc.clip(frames[:1], lookahead=0)[0]
+        else:
+            got = cc.clip(frames, lookahead=2)[0]
+        torch.cuda.synchronize()
+        fresh = ClipColorizer(*nets, temperature=1e-10)    # eager, same modules: packs the CURRENT weights
+        fresh.set_exemplar(IB)
+        want = fresh.frame(frames[0], zero)[0]
+        assert torch.equal(got, want), (step, (got - want).abs().max().item())
+        assert not torch.equal(got, ab0)
 
 
 def test_luminance_noise_path(nets):

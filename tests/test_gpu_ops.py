@@ -731,6 +731,143 @@ def test_corr_bf16_candidate_filter_is_exact(ops, h, w, B, mode):
         ops.corr_fwd_bf16(thb, phb, blab, 0.01, h, w)
 
 
+def _tie_case(h, w, k, layout, g):
+    """theta / phi / Lab map with k EXACTLY duplicated exemplar columns that carry different pooled colours, and a set of
+    query columns for which the duplicated key is the row maximum (theta = the duplicated phi column + 5 % noise, renormalised:
+    affinity ~0.99 to all k copies — bit-equal, since the copies are — against ~0.25 for the best random key).
+    layout: where the copies sit relative to the kernel's decomposition (csrc/corr.hip: 32-key tiles; a lane holds 16 keys of a
+    tile, lanes l and l ^ 32 the two halves; ~13-tile key ranges per workgroup at P = 5184, merged by corr_merge_kernel):
+      "tile"   all copies inside one 32-key tile (both lane halves);
+      "tiles"  spread over adjacent tiles (one workgroup's range for most query blocks, across a boundary for some);
+      "ranges" spread over the whole key axis (different workgroups' partial states: the merge must ADD the `l` sums and
+               colour sums of equal maxima)."""
+    P = h * w
+    phi = torch.randn(1, 256, P, generator=g)
+    phi = phi - phi.mean(-1, keepdim=True)
+    phi = phi / phi.norm(2, 1, keepdim=True)
+    j0 = (P // 3) // 32 * 32 + 3
+    if layout == "tile":
+        offs = [0, 1, 17, 9, 28][:k]
+    elif layout == "tiles":
+        offs = [0, 32, 65, 97, 130][:k]
+    else:
+        offs = [int(i * (P - j0 - 1) / max(k - 1, 1)) for i in range(k)]
+        offs[0] = 0
+    dups = [j0 + o for o in offs]
+    assert len(set(dups)) == k and max(dups) < P
+    phi[:, :, dups] = phi[:, :, j0:j0 + 1]
+    theta = torch.randn(1, 256, P, generator=g)
+    theta = theta - theta.mean(-1, keepdim=True)
+    theta = theta / theta.norm(2, 1, keepdim=True)
+    qs = torch.arange(5, P, 7)                              # crafted queries in every query block
+    tq = phi[:, :, j0:j0 + 1] + 0.05 * torch.randn(1, 256, qs.numel(), generator=g) / 16
+    theta[:, :, qs] = tq / tq.norm(2, 1, keepdim=True)
+    lab_map = torch.randn(1, 3, 4 * h, 4 * w, generator=g) * 30
+    return theta.contiguous(), phi.contiguous(), lab_map, dups, qs
+
+
+@pytest.mark.parametrize("T", [1e-10, 1e-4, 0.01])
+@pytest.mark.parametrize("h,w,k,layout", [(54, 96, 2, "tile"), (54, 96, 3, "tile"), (54, 96, 5, "tile"), (54, 96, 2, "tiles"),
+                                          (54, 96, 5, "tiles"), (54, 96, 2, "ranges"), (54, 96, 3, "ranges"), (54, 96, 5, "ranges"),
+                                          (13, 24, 3, "ranges"), (9, 9, 2, "tiles")])
+def test_corr_exact_ties_split_equally(ops, h, w, k, layout, T):
+    """The reference's exact-tie behaviour (models/NonlocalNet.py:487-488): duplicated exemplar columns give
+    bit-equal affinities, `f / T` collapses them onto one fp32 value and softmax splits the weight EQUALLY between them — at
+    test.py's T = 1e-10 the warped colour of a query whose best key is duplicated k times is the MEAN of the k pooled colours
+    (a letter-boxed or flat exemplar produces exactly this).  The fused kernel must reproduce it wherever the copies sit:
+    inside one 32-key tile, in several tiles of one workgroup's key range, in different workgroups' ranges (corr_merge_kernel
+    adds the sums of equal maxima).  Expected values: analytically (mean of the copies' pooled colours on the crafted rows)
+    AND the oracle's materialised path on the same fp32 theta / phi, whose own affinities are checked to tie bit for bit
+    (ATen's GEMM gives identical columns identical results); at T = 1e-4 / 0.01 (middle / soft regime of the kernel) the
+    oracle's soft weights, within the first-order bound of test_corr_fwd_vs_oracle."""
+    from oracle import dvc_oracle as O
+    g = torch.Generator().manual_seed(1000 * k + h + len(layout))
+    P = h * w
+    th, ph, lab_map, dups, qs = _tie_case(h, w, k, layout, g)
+    with torch.no_grad():
+        y_ref, sim_ref, f = O.correlate(th, ph, lab_map, T)
+    oracle_ties = all(torch.equal(f[0, :, dups[0]], f[0, :, d]) for d in dups[1:])
+    y64, sim64, am64, gap, S = _corr_truth(th, ph, lab_map, T)
+    blab = ops.avgpool4x4(lab_map.cuda()).view(1, 3, P)
+    out = ops.corr_fwd(th.cuda(), ph.cuda(), blab, T, h, w, want_small=True, want_argmax=True)
+    torch.cuda.synchronize()
+    y_hip = out["y_small"].cpu().double().view(1, 3, P)
+    amax = out["argmax"][0].cpu().long()
+    sim_err = (out["sim_small"].cpu() - sim_ref).abs().max().item()
+    # rows outside the crafted set with an accidental near-tie (gap <= 2e-6) are excluded as everywhere; the crafted rows have
+    # gap == 0 BY CONSTRUCTION and are the point of the test
+    crafted = torch.zeros(P, dtype=torch.bool)
+    crafted[qs] = True
+    rows = ((gap[0] > 2e-6) | crafted).view(1, 1, P).expand(1, 3, P)
+    r_oracle = ((y_hip - y_ref.double().view(1, 3, P)).abs() / _y_bound(S, T, 2))[rows].max().item()
+    r_truth = ((y_hip - y64).abs() / _y_bound(S, T, 1))[rows].max().item()
+    mean_col = blab.cpu().double()[0][:, dups].mean(-1)                                  # [3]
+    e_mean = (y_hip[0][:, qs] - mean_col[:, None]).abs().max().item()
+    in_dups = torch.isin(amax[qs], torch.tensor(dups)).all().item()
+    report(f"corr exact ties {h}x{w} k={k} {layout} T={T:g}: oracle affinities tie bit for bit: {oracle_ties}; crafted rows {qs.numel()}; "
+           f"sim_err={sim_err:.2e}; |y - mean of the k pooled colours| on crafted rows={e_mean:.2e}; err/bound vs oracle {r_oracle:.3f} "
+           f"vs fp64 {r_truth:.3f}; arg-max inside the duplicate set: {in_dups}")
+    assert oracle_ties, "precondition: the oracle's GEMM must give duplicated columns identical affinities"
+    assert sim_err < 2e-6 and in_dups
+    assert r_oracle <= 1.0 and r_truth <= 1.0
+    if T == 1e-10:
+        # equal split: the mean of the copies' colours (1e-5 + 4e-7 |B|: fp32 evaluation of (1/k) sum B_j)
+        assert e_mean <= 1e-5 + 4e-7 * blab.abs().max().item(), e_mean
+        # ... and NOT one of the copies' own colours (they differ by construction)
+        assert (y_hip[0][:, qs[0]] - blab.cpu().double()[0][:, dups[0]]).abs().max().item() > 1e-2
+    again = ops.corr_fwd(th.cuda(), ph.cuda(), blab, T, h, w, want_small=True)
+    assert torch.equal(again["y_small"], out["y_small"])
+
+
+@pytest.mark.parametrize("T", [1e-10, 1e-4])
+@pytest.mark.parametrize("h,w,k,layout", [(54, 96, 2, "tile"), (54, 96, 5, "tiles"), (54, 96, 5, "ranges"), (54, 96, 63, "spread"),
+                                          (54, 96, 64, "spread"), (54, 96, 65, "spread"), (54, 96, 70, "spread"), (13, 24, 3, "ranges")])
+def test_corr_bf16_exact_ties_split_equally(ops, h, w, k, layout, T):
+    """The same duplicated-column cases through the bf16 candidate filter + fp32 re-scoring (csrc/corr_bf16.hip): every copy
+    of the best key is a candidate (their bf16 affinities are bit-equal too), the re-scoring kernel applies the reference's
+    softmax(f / T) to the candidates — so k copies share the weight equally.  "spread" cases put k = 63 / 64 / 65 / 70 copies
+    on the key axis: around and beyond the 64-entry candidate list, where a query is re-scored against ALL keys."""
+    from oracle import dvc_oracle as O
+    g = torch.Generator().manual_seed(77 * k + h)
+    P = h * w
+    if layout == "spread":
+        th, ph, lab_map, dups, qs = _tie_case(h, w, 2, "ranges", g)
+        j0 = dups[0]
+        extra = [(j0 + 37 + 71 * i) % P for i in range(k - 1)]
+        dups = [j0] + extra
+        assert len(set(dups)) == k
+        ph[:, :, dups] = ph[:, :, j0:j0 + 1]
+    else:
+        th, ph, lab_map, dups, qs = _tie_case(h, w, k, layout, g)
+    with torch.no_grad():
+        y_ref, sim_ref, f = O.correlate(th, ph, lab_map, T)
+    assert all(torch.equal(f[0, :, dups[0]], f[0, :, d]) for d in dups[1:])
+    y64, sim64, am64, gap, S = _corr_truth(th, ph, lab_map, T)
+    blab = ops.avgpool4x4(lab_map.cuda()).view(1, 3, P)
+
+    def pair(t):     # ([B,P,C] fp32, [B,P,C] bf16 bit patterns, round-to-nearest-even) as dvc_corr_prepare_bf16 lays them out
+        t = t.transpose(1, 2).contiguous()
+        return t.cuda(), t.to(torch.bfloat16).view(torch.int16).cuda()
+
+    out = ops.corr_fwd_bf16(pair(th), pair(ph), blab, T, h, w, want_small=True, want_argmax=True)
+    torch.cuda.synchronize()
+    y_hip = out["y_small"].cpu().double().view(1, 3, P)
+    amax = out["argmax"][0].cpu().long()
+    crafted = torch.zeros(P, dtype=torch.bool)
+    crafted[qs] = True
+    rows = ((gap[0] > 2e-6) | crafted).view(1, 1, P).expand(1, 3, P)
+    sim_err = (out["sim_small"].cpu() - sim_ref).abs().max().item()
+    r_oracle = ((y_hip - y_ref.double().view(1, 3, P)).abs() / _y_bound(S, T, 2))[rows].max().item()
+    mean_col = blab.cpu().double()[0][:, dups].mean(-1)
+    e_mean = (y_hip[0][:, qs] - mean_col[:, None]).abs().max().item()
+    in_dups = torch.isin(amax[qs], torch.tensor(dups)).all().item()
+    report(f"corr_bf16 exact ties {h}x{w} k={k} {layout} T={T:g}: sim_err={sim_err:.2e}; |y - mean of the k pooled colours| on crafted "
+           f"rows={e_mean:.2e}; err/bound vs oracle {r_oracle:.3f}; arg-max inside the duplicate set: {in_dups}")
+    assert sim_err < 2e-6 and in_dups and r_oracle <= 1.0
+    if T == 1e-10:
+        assert e_mean <= 1e-5 + 4e-7 * blab.abs().max().item() * max(1, k // 8), e_mean
+
+
 @pytest.mark.parametrize("h,w,B,T,scale", [(12, 20, 1, 0.01, 0.5), (9, 9, 2, 0.01, 2.0), (27, 48, 1, 0.005, 0.7),
                                            (54, 96, 1, 0.01, 0.5), (10, 16, 1, 1e-10, 0.5), (12, 20, 1, 1e-4, 0.5),
                                            (27, 48, 1, 1e-6, 0.7), (10, 16, 2, 9e-4, 2.0)])

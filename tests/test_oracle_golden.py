@@ -153,3 +153,29 @@ def test_video_oracle_is_the_composition_of_its_parts():
             assert torch.equal(ab, ab_t)
             want, _ = tail_oracle.frame_tail(L[:, 0:1].numpy(), ab.numpy())
             assert g.dtype == np.uint8 and g.shape == (64, 96, 3) and np.array_equal(g, want)
+
+
+def test_c3_helper_recurrence_is_colorize_clip_when_nothing_flips():
+    """tests/c3_common.py (the oracle side of the configs[2] / configs[4] GPU tests) composes the oracle's functions itself —
+    exemplar side once, front end per frame, ColorVidNet recurrence with the other path's tie-breaks.  Pinned here: with the
+    oracle's OWN arg-max handed in as "the other path" it is oracle.colorize_clip bit for bit, and a flipped row changes
+    exactly that row's colour to the pooled colour of the position handed in."""
+    import c3_common as C
+    torch.set_num_threads(1)
+    H, W, T = 48, 80, 1e-10
+    sd = (synth.vgg19_state_dict(0), synth.warpnet_state_dict(0), synth.colorvidnet_state_dict(0, contractive=True))
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
+    frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W) for i in range(3)]
+    phi = C.oracle_exemplar(sd, IB)
+    fronts = [C.oracle_front(sd, IB, phi, fr, T) for fr in frames]
+    same = [dict(argmax=f["argmax"].clone(), sim_small=f["sim_small"], y_small=f["y_small"]) for f in fronts]
+    got, stats = C.matched_oracle_chunk(sd, IB, frames, fronts, same)
+    with torch.no_grad():
+        want = O.colorize_clip(frames, IB, *sd, temperature=T)
+    for a, b, st in zip(got, want, stats):
+        assert torch.equal(a, b) and st["flipped"] == 0 and st["y_err"] == 0.0
+    other = [dict(argmax=f["argmax"].clone(), sim_small=f["sim_small"], y_small=f["y_small"]) for f in fronts]
+    other[1]["argmax"][7] = (other[1]["argmax"][7] + 11) % (H // 4 * W // 4)
+    got2, stats2 = C.matched_oracle_chunk(sd, IB, frames, fronts, other)
+    assert torch.equal(got2[0], want[0]) and stats2[1]["flipped"] == 1
+    assert not torch.equal(got2[1], want[1]) and not torch.equal(got2[2], want[2])     # the flip propagates along the recurrence
