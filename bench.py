@@ -443,6 +443,24 @@ def main():
         t_eager, last_eager = median_s(eager_clip, side_reps)
         eager_fps = K / t_eager
         assert torch.equal(last_eager, last_timed), "hipGraph replay != eager launches"
+    # ... and the multi-reference pass (test.py:169-181 colourises the same clip once per reference image): the same K frames
+    # against R exemplars at once — one front end per frame, R correlations, ColorVidNet chain at batch R (set_exemplars)
+    multi = None
+    if args.refs > 1 and args.lookahead > 0 and rank == 0 and not args.no_exemplar_cache:
+        ref_seeds = [synth.EXEMPLAR_SEED, 3, 5, 11, 13, 17, 19, 23][:args.refs]
+        cc_m = ClipColorizer(*nets, temperature=1e-10)
+        cc_m.set_exemplars([synth.synth_lab(sd_, H, W).to(device) for sd_ in ref_seeds])
+        cc_m.clip(frames[:max(Wm, 2)], lookahead=args.lookahead)             # warm-up (autotune at batch R, stream pools)
+
+        def refs_clip():
+            return cc_m.clip(frames[Wm:Wm + K], lookahead=args.lookahead)[-1]
+        t_m, ab_m = median_s(refs_clip, side_reps)
+        assert torch.isfinite(ab_m).all()
+        multi = {"R": len(ref_seeds), "frame_colorizations_per_s": round(len(ref_seeds) * K / t_m, 3),
+                 "clip_frames_per_s": round(K / t_m, 3), "ms_per_clip_frame": round(t_m / K * 1e3, 4),
+                 "note": "the K timed frames against R exemplars in one pass (ClipColorizer.set_exemplars): one VGG19 + WarpNet "
+                         "front end per frame, R fused correlations, ColorVidNet at batch R with a batch-aware launch plan; "
+                         "compare frame_colorizations_per_s with `value` (R passes, one reference each)"}
     last = last_timed
     t = torch.tensor(rep_s, device=device, dtype=torch.float64)
     if use_dist:
@@ -547,7 +565,9 @@ def main():
                                     "eager launches (fixed mode, no warm-up trial)") if use_graph else
                                    (graph_note or "every kernel launched from Python"),
                        "per_frame_api_frames_per_s": None if seq_fps is None else round(seq_fps, 3),
-                       "eager_launch_clip_driver_frames_per_s": None if eager_fps is None else round(eager_fps, 3)},
+                       "eager_launch_clip_driver_frames_per_s": None if eager_fps is None else round(eager_fps, 3),
+                       "multi_reference": None if multi is None else dict(
+                           multi, speedup_vs_one_pass_per_reference=round(multi["frame_colorizations_per_s"] / (fps / n_gpus), 3))},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

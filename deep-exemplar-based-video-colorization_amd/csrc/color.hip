@@ -94,9 +94,10 @@ extern "C" int dvc_pack_color_input(const float* IA_l, int64_t ia_batch_stride, 
     DVC_REQUIRE(IA_l && warped_lab && sim && last_l && last_ab && out7 && N > 0 && HW > 0,
                 "dvc_pack_color_input: bad argument");
     hipLaunchKernelGGL(pack_color_input_kernel, dim3(cdiv(HW, 1024), N), dim3(256), 0,
-                       (hipStream_t)stream, IA_l, ia_batch_stride ? (long)ia_batch_stride : (long)HW, warped_lab, sim, last_l,
-                       last_l_batch_stride ? (long)last_l_batch_stride : (long)HW, last_ab,
-                       last_ab_batch_stride ? (long)last_ab_batch_stride : 2L * HW, (long)HW, out7);
+                       (hipStream_t)stream, IA_l, ia_batch_stride < 0 ? 0L : ia_batch_stride ? (long)ia_batch_stride : (long)HW,
+                       warped_lab, sim, last_l,
+                       last_l_batch_stride < 0 ? 0L : last_l_batch_stride ? (long)last_l_batch_stride : (long)HW, last_ab,
+                       last_ab_batch_stride < 0 ? 0L : last_ab_batch_stride ? (long)last_ab_batch_stride : 2L * HW, (long)HW, out7);
     DVC_CHECK_LAUNCH("dvc_pack_color_input");
     return 0;
 }

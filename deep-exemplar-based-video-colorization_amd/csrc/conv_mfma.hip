@@ -472,12 +472,15 @@ static void wino_plan(const DvcConvDesc* d, int OH, int OW, bool have_workspace,
         for (int ti = 0; ti < 4; ++ti) {
             const int tr = kTR[ti];
             if (shape_cfg >= 0 && shape_cfg % 4 != ti) continue;
-            // (workgroups of ONE image: the plan never depends on the batch size, see conv2d_images)
-            const long wgs = (long)ss * ss * cdiv(TY, tr * wn) * cdiv(TX, 32 / tr) * (d->Cout / (32 * wm));
+            // (workgroups of ONE image: the plan never depends on the batch size, see conv2d_images — unless the caller asks
+            // for a plan of the whole batch, DVC_CONV_BATCH_PLAN: the R references of a clip run in lock step anyway)
+            const long wgs = (long)ss * ss * cdiv(TY, tr * wn) * cdiv(TX, 32 / tr) * (d->Cout / (32 * wm)) *
+                             ((d->flags & DVC_CONV_BATCH_PLAN) ? d->N : 1);
             for (int S = 1; S <= 8; ++S) {
                 if (d->split_k > 0 && S != d->split_k) continue;
                 if (S > 1 && (!have_workspace || S > nch / 2 ||
-                              (size_t)S * d->Cout * OH * OW * sizeof(float) > workspace_bytes)) continue;
+                              (size_t)S * d->Cout * OH * OW * sizeof(float) * ((d->flags & DVC_CONV_BATCH_PLAN) ? d->N : 1) >
+                                  workspace_bytes)) continue;
                 const int cps = cdiv(nch, S);
                 if (cdiv(nch, cps) != S) continue;
                 const double rounds = (double)cdivl(wgs * S, (long)ncu * kWinoShapes[m].per_cu);

@@ -17,7 +17,13 @@ frames' front ends on side HIP streams, x2 bilinear * 1.25, fast global smoother
   the output folder is `<output_path>/<clip>_<reference stem>` and every reference image of --ref_path is tried, errors
   are printed and skipped (test.py:168-181).
 Extra, optional flags (not upstream): --vgg_path/--nonlocal_path/--colornet_path (the upstream paths are the defaults),
---synthetic_weights (no checkpoints at hand: deterministic synthetic weights), --batch_frames.
+--synthetic_weights (no checkpoints at hand: deterministic synthetic weights), --batch_frames, --refs_per_pass.
+
+The per-reference loop (test.py:169-181: the SAME clip colourised once per reference image; the sample set ships 3-6
+references per clip) is re-designed rather than transcribed: R references are R independent recurrences over the same
+frames, so `colorize_video_refs` decodes / ingests every frame ONCE, runs ONE VGG19 + WarpNet front end per frame, R fused
+correlations (theta shared) and the ColorVidNet chain at batch R (ClipColorizer.set_exemplars), and writes the R output
+folders the loop would have written.  `--refs_per_pass 1` restores one pass per reference.
 """
 import argparse
 import glob
@@ -159,6 +165,45 @@ def colorize_video(opt, input_path, reference_file, output_path, nonlocal_net, c
     print()
 
 
+def colorize_video_refs(opt, input_path, reference_files, output_paths, nonlocal_net, colornet, vggnet):
+    """`colorize_video` for all reference images of a clip in ONE pass over the frames: what test.py:169-181's loop
+    `for ref_name in refs: colorize_video(...)` produces — folder `output_paths[r]` with `00000.jpg ...` and `video.avi` for
+    reference `reference_files[r]` — with the frame decode / ingest and the frame-side front end done once per frame instead of
+    once per (frame, reference).  With --frame_propagate the reference file is ignored upstream (test.py:50): the R folders
+    receive the same frames, computed once."""
+    from .frame import ClipColorizer
+    wls_filter_on, lambda_value, sigma_color = True, 500, 4
+    for o in output_paths:
+        mkdir_if_not(o)
+    print("processing the folder:", input_path)
+    path, dirs, filenames = os.walk(input_path).__next__()
+    filenames.sort(key=lambda f: int("".join(filter(str.isdigit, f) or -1)))
+    device = torch.device("cuda", torch.cuda.current_device())
+    propagate = bool(opt.frame_propagate)
+    for r in reference_files:
+        print("reference name:", input_path + filenames[0] if propagate else r)
+    refs = None if propagate else [_load_rgb8(r, device) for r in reference_files]
+    if propagate:
+        _load_rgb8(input_path + filenames[0], device)
+    cc = ClipColorizer(vggnet, nonlocal_net, colornet, temperature=1e-10)
+    batch = max(1, int(getattr(opt, "batch_frames", 32)))
+    index = 0
+    with torch.no_grad():
+        for b0 in range(0, len(filenames), batch):
+            frames = [_load_rgb8(os.path.join(input_path, f), device) for f in filenames[b0:b0 + batch]]
+            rgbs = cc.colorize_video(frames, refs if (refs is None or len(refs) > 1) else refs[0], image_size=opt.image_size,
+                                     wls_filter_on=wls_filter_on, lambda_value=lambda_value, sigma_color=sigma_color,
+                                     frame_propagate=propagate, continue_clip=b0 > 0)
+            for per_ref in rgbs:
+                images = per_ref if isinstance(per_ref, list) else [per_ref] * len(output_paths)
+                for image, o in zip(images, output_paths):
+                    save_frames(image.cpu().numpy(), o, index)
+                index += 1
+    for o in output_paths:
+        folder2vid(image_folder=o, output_dir=o, filename="video.avi")
+    print()
+
+
 def build_parser():
     parser = argparse.ArgumentParser()
     parser.add_argument("--frame_propagate", default=False, type=bool, help="propagation mode, , please check the paper")
@@ -174,6 +219,8 @@ def build_parser():
     parser.add_argument("--colornet_path", type=str, default=os.path.join("checkpoints/", "video_moredata_l1/colornet_iter_76000.pth"))
     parser.add_argument("--synthetic_weights", action="store_true", help="deterministic synthetic weights instead of checkpoints")
     parser.add_argument("--batch_frames", type=int, default=32, help="frames decoded and colourised per device batch")
+    parser.add_argument("--refs_per_pass", type=int, default=8,
+                        help="reference images colourised in one pass over the clip (1 = one pass per reference, as upstream)")
     return parser
 
 
@@ -214,14 +261,27 @@ def main(argv=None):
     colornet.cuda()
     vggnet.cuda()
 
-    for ref_name in refs:
-        try:
-            colorize_video(opt, opt.clip_path, os.path.join(opt.ref_path, ref_name),
-                           os.path.join(opt.output_path, clip_name + "_" + ref_name.split(".")[0]),
-                           nonlocal_net, colornet, vggnet)
-        except Exception as error:
-            print("error when colorizing the video " + ref_name)
-            print(error)
+    per_pass = max(1, int(opt.refs_per_pass))
+    out_of = lambda ref_name: os.path.join(opt.output_path, clip_name + "_" + ref_name.split(".")[0])     # noqa: E731
+    for g0 in range(0, len(refs), per_pass):
+        group = refs[g0:g0 + per_pass]
+        if len(group) > 1:
+            # all references of the group in one pass over the clip; a reference that cannot be colourised (unreadable
+            # image, ...) must not take the others down with it, so a failed group falls back to the upstream loop
+            try:
+                colorize_video_refs(opt, opt.clip_path, [os.path.join(opt.ref_path, r) for r in group],
+                                    [out_of(r) for r in group], nonlocal_net, colornet, vggnet)
+                continue
+            except Exception as error:
+                print("error when colorizing the video with references " + ", ".join(group) + " in one pass; one by one:")
+                print(error)
+        for ref_name in group:
+            try:
+                colorize_video(opt, opt.clip_path, os.path.join(opt.ref_path, ref_name), out_of(ref_name),
+                               nonlocal_net, colornet, vggnet)
+            except Exception as error:
+                print("error when colorizing the video " + ref_name)
+                print(error)
 
     video_name = "video.avi"
     clip_output_path = os.path.join(opt.output_path, clip_name)

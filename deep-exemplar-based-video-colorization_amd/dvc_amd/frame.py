@@ -109,6 +109,7 @@ class ClipColorizer:
         self.IB_lab = None
         self.features_B = None
         self.ex_cache = None
+        self.n_refs = 1              # R > 1 after set_exemplars(): every frame is colourised against R references at once
         self.last_lab = None         # [L, ab] of the last frame colourised by clip()
         self._side_streams = []
         self._main_stream = None
@@ -137,6 +138,7 @@ class ClipColorizer:
         """test.py:61-66: Lab -> RGB -> VGG features of the reference image."""
         IB_lab = IB_lab.detach().contiguous().float()
         self.IB_lab = IB_lab
+        self.n_refs = 1                            # (set_exemplars raises it after this call)
         rgb = ops.lab2rgb(IB_lab, l_offset=50.0)   # uncenter_l folded into the kernel
         self.features_B = self.vgg(rgb, VGG_OUT, preprocess=True)
         old = self.ex_cache
@@ -146,6 +148,35 @@ class ClipColorizer:
             new = self.warp.exemplar_side(IB_lab, *nB, bf16=self.warp._use_bf16(self.temperature, 1))
             self.ex_cache = self._install_cache(old, new)
         return self.features_B
+
+    def set_exemplars(self, IB_labs):
+        """All references of a clip in ONE pass (/root/reference/test.py:169-181 colourises the same clip once per reference
+        image: R independent recurrences over the SAME frames).  `IB_labs`: a list of [1,3,H,W] Lab references (or one
+        [R,3,H,W] tensor).  After this call `clip` / `clip_rgb` / `colorize_video` take the clip's frames ([1,3,H,W] each)
+        and return, per frame, the R predictions as one [R,2,H,W] tensor: per frame ONE VGG19(A) + WarpNet(A) front end (114
+        of the 348 GFLOP of a frame, identical for every reference), R fused correlations (theta shared; phi / pooled Lab per
+        reference), and the ColorVidNet chain at batch R under a batch-aware launch plan (ops.batch_plan: layers that one
+        image under-fills drop their split over input channels).  Front-end results are bit-identical to R single-reference
+        runs; ab agrees with them to fp32 rounding of the convolutions' summation order (tests/test_gpu_refs.py states the
+        measured numbers) and with the oracle per reference within the north-star 1e-3."""
+        IB = torch.cat(list(IB_labs), dim=0) if not isinstance(IB_labs, torch.Tensor) else IB_labs
+        if not self.cache_exemplar:
+            raise RuntimeError("ClipColorizer.set_exemplars needs cache_exemplar=True (the references' WarpNet sides are cached)")
+        feats = self.set_exemplar(IB)            # batch R: every launch planned per image -> each reference's cache is
+        self.n_refs = IB.shape[0]                # bit-identical to the one set_exemplar(IB[r]) builds
+        return feats
+
+    def _rep(self, x):
+        """A [1,...] tensor seen as [R,...] (batch stride 0: nothing is copied) in multi-reference mode."""
+        return x.expand(self.n_refs, -1, -1, -1) if self.n_refs > 1 and x.shape[0] == 1 else x
+
+    def _chain(self, cin):
+        """The ColorVidNet chain; in multi-reference mode the R recurrences advance in lock step as ONE batch, planned as a
+        batch (DVC_CONV_BATCH_PLAN)."""
+        if self.n_refs > 1:
+            with ops.batch_plan(True):
+                return self.col(cin)
+        return self.col(cin)
 
     def _install_cache(self, old, new):
         """Captured front ends read the exemplar cache at the addresses it had at capture time: a new exemplar of the same
@@ -237,6 +268,12 @@ class ClipColorizer:
 
     def frame(self, IA_lab, IA_last_lab, graph=None):
         """One frame_colorization call (the per-frame API of test.py:85): returns (ab, warped Lab)."""
+        if self.n_refs > 1:     # one frame against the R references: IA_last_lab [R,3,H,W] -> (ab [R,2,H,W], warped [R,3,H,W])
+            IA_lab = IA_lab.detach().contiguous().float()
+            warped, sim, _ = warp_color(IA_lab[:, 0:1], self.IB_lab, None, self.vgg, self.warp, self.col, 0,
+                                        temperature=self.temperature, exemplar_cache=self.ex_cache)
+            cin = ops.pack_color_input(self._rep(IA_lab), warped, sim, IA_last_lab.detach().contiguous().float())
+            return self._chain(cin), warped
         if self.graph if graph is None else graph:
             return self._frame_graph(IA_lab.detach().contiguous().float(),
                                      dict(IA_last_lab=IA_last_lab.detach().contiguous().float()))
@@ -283,11 +320,21 @@ class ClipColorizer:
         if not frames_lab:
             return []
         use_graph = self.graph if graph is None else bool(graph)
+        multi = self.n_refs > 1
+        if multi:
+            # R references in one pass: the frames are single images, every per-frame result carries R images; the captured
+            # sequences hold one image per slot, so this mode issues its launches from Python
+            if frame_propagate:
+                raise ValueError("ClipColorizer.clip: frame_propagate uses the clip's first frame as THE exemplar; it has no "
+                                 "multi-reference form (test.py:50 ignores the reference file in that mode)")
+            if any(f.shape[0] != 1 for f in frames_lab):
+                raise ValueError("ClipColorizer.clip: multi-reference mode takes [1,3,H,W] frames")
+            use_graph, front_batch = False, 1
         if use_graph and int(front_batch) > 1:
             raise ValueError("ClipColorizer.clip: front_batch > 1 is not available with graph=True (a captured front end "
                              "holds one frame per slot); pass graph=False or front_batch=1")
         if last is None:
-            last = self.IB_lab if frame_propagate else torch.zeros_like(frames_lab[0])
+            last = self.IB_lab if frame_propagate else torch.zeros_like(self._rep(frames_lab[0]))
         last = last.detach().contiguous().float()
         prev = dict(IA_last_lab=last)          # how the previous frame is handed to pack_color_input
         outs = []
@@ -299,12 +346,12 @@ class ClipColorizer:
                     IA_l = IA_lab[:, 0:1]
                     warped, sim, _ = warp_color(IA_l, self.IB_lab, self.features_B, self.vgg, self.warp, self.col, 0,
                                                 temperature=self.temperature, exemplar_cache=self.ex_cache)
-                    ab = self.col(ops.pack_color_input(IA_lab, warped, sim, **prev))
-                prev = dict(last_l=IA_lab, last_ab=ab)
+                    ab = self._chain(ops.pack_color_input(self._rep(IA_lab), warped, sim, **prev))
+                prev = dict(last_l=self._rep(IA_lab), last_ab=ab)
                 outs.append(ab)
                 if on_frame is not None:
                     on_frame(len(outs) - 1, IA_lab, ab)
-            self.last_lab = torch.cat((frames_lab[-1][:, 0:1], outs[-1]), dim=1)   # test.py:96 (pure data movement)
+            self.last_lab = torch.cat((self._rep(frames_lab[-1])[:, 0:1], outs[-1]), dim=1)   # test.py:96 (pure data movement)
             return outs
         caller = torch.cuda.current_stream()
         # every lazily packed weight is produced here, on the caller's stream, before the fork: a side
@@ -343,17 +390,20 @@ class ClipColorizer:
             for x in (IA_b, warped_b, sim_b):
                 x.record_stream(cur)    # allocated on a side stream, consumed here
             for j, t in enumerate(members):
-                IA_lab, warped, sim = IA_b[j:j + 1], warped_b[j:j + 1], sim_b[j:j + 1]
+                if multi:       # (one frame per set of front-end launches; its warped colours / similarity carry R images)
+                    IA_lab, warped, sim = self._rep(IA_b), warped_b, sim_b
+                else:
+                    IA_lab, warped, sim = IA_b[j:j + 1], warped_b[j:j + 1], sim_b[j:j + 1]
                 with torch.cuda.stream(cur):
-                    ab = self.col(ops.pack_color_input(IA_lab, warped, sim, **prev))
-                    prev = dict(last_l=frames_lab[t], last_ab=ab)
+                    ab = self._chain(ops.pack_color_input(IA_lab, warped, sim, **prev))
+                    prev = dict(last_l=self._rep(frames_lab[t]), last_ab=ab)
                     if on_frame is not None:
                         on_frame(t, IA_lab, ab)
                 outs.append(ab)
                 if j == 0 and bi + lookahead < len(batches):   # (issued after the critical-path launches of the frame)
                     launch_front(bi + lookahead)
         with torch.cuda.stream(cur):
-            last = torch.cat((frames_lab[-1][:, 0:1], outs[-1]), dim=1)     # test.py:96, once per call
+            last = torch.cat((self._rep(frames_lab[-1])[:, 0:1], outs[-1]), dim=1)     # test.py:96, once per call
         caller.wait_stream(cur)
         for x in outs + [last]:
             x.record_stream(caller)     # allocated on the recurrence stream, handed to the caller's stream
@@ -448,14 +498,19 @@ class ClipColorizer:
             ev = torch.cuda.Event()
             ev.record()                         # on the stream that produced the newest `ab`
             ts.wait_event(ev)
-            idx = [t for t, _ in pending]
+            R = self.n_refs
+            idx = [t for t, _ in pending for _ in range(R)]                        # (R tails per frame in multi-reference mode)
             for _, ab in pending:
                 ab.record_stream(ts)
             with torch.cuda.stream(ts):
-                out, _ = tail.frames_tail([frames_lab_large[t] for t in idx], [ab for _, ab in pending],
+                out, _ = tail.frames_tail([frames_lab_large[t] for t in idx], [ab[r:r + 1] for _, ab in pending for r in range(R)],
                                           wls_filter_on, lambda_value, sigma_color)
-            for t, r in zip(idx, out):
-                rgbs[t] = r
+            if R == 1:
+                for t, r in zip(idx, out):
+                    rgbs[t] = r
+            else:
+                for i, (t, _) in enumerate(pending):
+                    rgbs[t] = out[i * R:(i + 1) * R]
             pending.clear()
 
         def on_frame(t, IA_lab, ab):
@@ -466,7 +521,8 @@ class ClipColorizer:
         self.clip(small, frame_propagate=frame_propagate, last=last, lookahead=lookahead, on_frame=on_frame)
         caller.wait_stream(ts)
         for x in rgbs:
-            x.record_stream(caller)
+            for y in (x if isinstance(x, list) else [x]):
+                y.record_stream(caller)
         return rgbs
 
     def colorize_video(self, frames_rgb8, reference_rgb8=None, image_size=(432, 768), wls_filter_on=True,
@@ -475,7 +531,9 @@ class ClipColorizer:
         colourised frames (image_size) out.  `image_size` is the size CenterPad produces (twice the network
         resolution; the reference's --image_size is the network resolution and test.py:163 doubles it).
         With frame_propagate=True the first frame is the exemplar and `reference_rgb8` is ignored, exactly as
-        test.py:50 ignores `reference_file` in that mode."""
+        test.py:50 ignores `reference_file` in that mode.
+        `reference_rgb8` may be a LIST of R reference images: the clip is then colourised against all of them in one pass
+        (set_exemplars) and every element of the result is a list of R images."""
         from . import tail
         large = [tail.frame_ingest(f, image_size) for f in frames_rgb8]
         if continue_clip:
@@ -485,6 +543,9 @@ class ClipColorizer:
             return self.clip_rgb(large, wls_filter_on, lambda_value, sigma_color, last=self.last_lab)
         if not frame_propagate and reference_rgb8 is None:
             raise ValueError("colorize_video: reference_rgb8 is required unless frame_propagate=True")
+        if not frame_propagate and isinstance(reference_rgb8, (list, tuple)):
+            self.set_exemplars([tail.downsample_half(tail.frame_ingest(r, image_size)) for r in reference_rgb8])
+            return self.clip_rgb(large, wls_filter_on, lambda_value, sigma_color)
         ref_large = large[0] if frame_propagate else tail.frame_ingest(reference_rgb8, image_size)
         self.set_exemplar(tail.downsample_half(ref_large))                      # test.py:57-66
         return self.clip_rgb(large, wls_filter_on, lambda_value, sigma_color, frame_propagate=frame_propagate)

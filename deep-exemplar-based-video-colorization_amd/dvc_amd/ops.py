@@ -198,6 +198,36 @@ def winograd_eligible(Cin, Cout, ksize=3, stride=1, dil=1, pad=1, in_affine=Fals
 
 
 DEFER_REDUCE = 1     # DVC_CONV_DEFER_REDUCE
+BATCH_PLAN = 2       # DVC_CONV_BATCH_PLAN
+_batch_plan = False
+
+
+class batch_plan:
+    """While active, Winograd launches that carry a batch are planned for the WHOLE batch (DVC_CONV_BATCH_PLAN): the images'
+    workgroups fill the chip together, so under-filled layers drop (part of) their split over input channels — no partial
+    sums, no reduce.  Results are deterministic per batch size but no longer bit-identical to single-image calls (the fp32
+    summation order over input channels follows the split).  Off by default: everywhere else a batch of N equals N calls bit
+    for bit.  Used by the multi-reference clip driver (ClipColorizer.clip_refs), whose R recurrences must run together."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _batch_plan
+        self.prev, _batch_plan = _batch_plan, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _batch_plan
+        _batch_plan = self.prev
+
+
+def batch_plan_enabled():
+    return _batch_plan
+
+
+def _plan_flags(N):
+    return BATCH_PLAN if (_batch_plan and N > 1) else 0
 _conv_ws_generation = {}     # convolution workspace (one per device and stream) -> number of convolutions that have used it
 
 
@@ -239,7 +269,7 @@ def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_
     if residual is not None:
         assert tuple(residual.shape) == (N, Cout, OH, OW), (residual.shape, (N, Cout, OH, OW))
     d = DvcConvDesc(N, Cin, H, W, Cout, 3, 1, dil, dil, pad_mode, in_up, in_sub, act, float(act_slope), 0, cfg, split_k,
-                    0, out_batch_stride, 0, 0)
+                    0, out_batch_stride, 0, _plan_flags(N))
     if conv_record is not None:
         conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=3, stride=1, dil=dil, pad=dil, pad_mode=pad_mode,
                                 in_up=in_up, in_sub=in_sub, affine=False, in_prelu=False, residual=residual is not None,
@@ -255,7 +285,7 @@ def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_
         # (a batch the library would cover in several launches - workspace capacity, 65535-workgroup cap - takes the
         # ordinary reduce: the deferred partial sums must be those of the whole batch)
         if S > 1 and ipl.value >= N and S * N * Cout * OH * OW * 4 <= ws.numel():
-            d.flags = DEFER_REDUCE
+            d.flags |= DEFER_REDUCE
         else:
             S = 1
     if S == 1 and out is None:
@@ -290,7 +320,7 @@ def conv2d_winograd_pool(x, u_packed, bias, *, act=ACT_NONE, act_slope=0.0, act_
     N, Cin, H, W = x.shape
     assert u_packed.dim() == 5 and u_packed.shape[1] == Cin and tuple(u_packed.shape[2:]) == (4, 32, 4), u_packed.shape
     Cout = u_packed.shape[0] * 32
-    d = DvcConvDesc(N, Cin, H, W, Cout, 3, 1, 1, 1, pad_mode, 1, 1, act, float(act_slope), 0, -1, 0, 0, 0, 0, 0)
+    d = DvcConvDesc(N, Cin, H, W, Cout, 3, 1, 1, 1, pad_mode, 1, 1, act, float(act_slope), 0, -1, 0, 0, 0, 0, _plan_flags(N))
     if conv_record is not None:
         conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=3, stride=1, dil=1, pad=1, pad_mode=pad_mode,
                                 in_up=1, in_sub=1, affine=False, in_prelu=False, residual=False, act=act, algo="winograd"))
@@ -319,7 +349,7 @@ def conv2d_winograd_dual(xA, xB, u_cat, bias, *, dil=1, pad_mode=PAD_ZERO, in_up
     if (OH, OW) != conv_out_hw(HB, WB, 3, 1, dil, dil, in_upB, 1):
         raise RuntimeError(f"dvc_amd: conv2d_winograd_dual: the two inputs' virtual sizes differ ({HA * in_upA} x {WA * in_upA} vs "
                            f"{HB * in_upB} x {WB * in_upB})")
-    dA = DvcConvDesc(N, CA, HA, WA, Cout, 3, 1, dil, dil, pad_mode, in_upA, 1, act, float(act_slope), 0, -1, 0, 0, 0, 0, 0)
+    dA = DvcConvDesc(N, CA, HA, WA, Cout, 3, 1, dil, dil, pad_mode, in_upA, 1, act, float(act_slope), 0, -1, 0, 0, 0, 0, _plan_flags(N))
     dB = DvcConvDesc(N, CB, HB, WB, Cout, 3, 1, dil, dil, pad_mode, in_upB, 1, act, float(act_slope), 0, -1, 0, 0, 0, 0, 0)
     if conv_record is not None:
         conv_record.append(dict(N=N, Cin=CA + CB, H=OH, W=OW, Cout=Cout, ksize=3, stride=1, dil=dil, pad=dil, pad_mode=pad_mode,
@@ -392,6 +422,11 @@ def _wino_rule(N, Cin, Cout, OH, OW, dil):
     # measured on the MI355X (profiles/r02_conv_algo_sweep.txt): with the two-workgroups-per-CU shape Winograd is faster than
     # or level with the direct engine on every eligible layer of the network down to the 13x24 feature maps
     # (per image, never a function of the batch size: a batch must run the kernels its images would run alone)
+    # r03 sweep (profiles/r03_conv_algo_sweep.txt): the one eligible layer where the direct engine wins is WarpNet's 128 -> 64
+    # at 54x96 (21.9 vs 22.5 us: a single 64-channel block of a 0.76-GFLOP layer leaves the Winograd kernel's position-split
+    # workgroups nothing to amortise their prologue over)
+    if Cout == 64 and Cin == 128 and dil == 1 and OH * OW <= 54 * 96:
+        return False
     return OH * OW >= 13 * 24
 
 
@@ -648,7 +683,9 @@ def _plane(t, ch, name):
     N, C, H, W = t.shape
     if t.stride(3) != 1 or t.stride(2) != W or (C > 1 and t.stride(1) != H * W):
         raise RuntimeError(f"dvc_amd: `{name}` must have dense planes (a contiguous tensor or a channel slice of one)")
-    return ctypes.c_void_p(t.data_ptr() + 4 * ch * H * W), (t.stride(0) if N > 1 else C * H * W)
+    # (an expanded tensor — one frame seen as R images, ClipColorizer._rep — has batch stride 0, which the C-ABI spells -1:
+    # 0 is its "densely packed" default)
+    return ctypes.c_void_p(t.data_ptr() + 4 * ch * H * W), ((t.stride(0) or -1) if N > 1 else C * H * W)
 
 
 def pack_color_input(IA_lab, warped_lab, sim, IA_last_lab=None, *, last_l=None, last_ab=None, out=None):
@@ -729,14 +766,21 @@ def _workspace(device, nbytes, tag="corr"):
 def corr_fwd(theta, phi, blab, temperature, h, w, wta_scale=1.0, want_small=False, want_argmax=False,
              want_up=True):
     """Fused affinity + softmax + colour gather.  theta/phi: [B,256,P]; blab: [B,3,P] (P = h*w).
-    Returns dict with y_up [B,3,4h,4w], sim_up [B,1,4h,4w] and optionally y_small / sim_small / argmax."""
+    Returns dict with y_up [B,3,4h,4w], sim_up [B,1,4h,4w] and optionally y_small / sim_small / argmax.
+    Batch forms: paired (theta, phi, blab all [B]); one exemplar for B frames (phi / blab [1]: the clip driver's batched
+    front ends); ONE FRAME AGAINST R EXEMPLARS (theta [1], phi / blab [R]: the references of a clip colourised in one pass,
+    test.py:169-181) — outputs then have R images.  The library runs one image per set of launches in every form, so an
+    image's result never depends on the form it came in."""
     lib = _lib.load()
     for t, nm in ((theta, "theta"), (phi, "phi"), (blab, "blab")):
         _need(t, nm)
-    B, C, P = theta.shape
-    shared = B > 1 and phi.shape[0] == 1 and blab.shape[0] == 1     # one exemplar for a batch of frames (clip driver)
+    Bt, C, P = theta.shape
+    R = phi.shape[0]
+    shared = Bt > 1 and R == 1 and blab.shape[0] == 1        # one exemplar for a batch of frames (clip driver)
+    refs = Bt == 1 and R > 1 and blab.shape[0] == R          # one frame against R exemplars
+    B = max(Bt, R)
     assert P == h * w and tuple(phi.shape[1:]) == (C, P) and blab[0].numel() == 3 * P
-    assert shared or (phi.shape[0] == B and blab.shape[0] == B), (theta.shape, phi.shape, blab.shape)
+    assert shared or refs or (R == Bt and blab.shape[0] == Bt), (theta.shape, phi.shape, blab.shape)
     if not (temperature > 0):
         raise ValueError("temperature must be > 0")
     dev = theta.device
@@ -750,12 +794,12 @@ def corr_fwd(theta, phi, blab, temperature, h, w, wta_scale=1.0, want_small=Fals
         sim_small = torch.empty((B, 1, h, w), device=dev, dtype=torch.float32)
     if want_argmax:
         amax = torch.empty((B, P), device=dev, dtype=torch.int32)
-    nbytes = lib.dvc_corr_workspace_bytes(B, P)
+    nbytes = lib.dvc_corr_workspace_bytes(1 if (shared or refs) else B, P)
     ws = _workspace(dev, nbytes)
 
-    def call(th, nb, sl):
+    def call(th, ph, bl, nb, sl):
         o = [None if t is None else t[sl] for t in (y_small, sim_small, y_up, sim_up)]
-        rc = lib.dvc_corr_fwd(_p(th), _p(phi), _p(blab), float(temperature), float(wta_scale), nb, C, h, w,
+        rc = lib.dvc_corr_fwd(_p(th), _p(ph), _p(bl), float(temperature), float(wta_scale), nb, C, h, w,
                               _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]),
                               None if amax is None else ctypes.c_void_p(amax[sl].data_ptr()),
                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
@@ -763,9 +807,12 @@ def corr_fwd(theta, phi, blab, temperature, h, w, wta_scale=1.0, want_small=Fals
 
     if shared:      # the library runs one image per set of launches anyway (results independent of the batch size)
         for b in range(B):
-            call(theta[b:b + 1], 1, slice(b, b + 1))
+            call(theta[b:b + 1], phi, blab, 1, slice(b, b + 1))
+    elif refs:
+        for r in range(R):
+            call(theta, phi[r:r + 1], blab[r:r + 1], 1, slice(r, r + 1))
     else:
-        call(theta, B, slice(0, B))
+        call(theta, phi, blab, B, slice(0, B))
     out.update(y_up=y_up, sim_up=sim_up, y_small=y_small, sim_small=sim_small, argmax=amax)
     return out
 
@@ -786,13 +833,17 @@ def corr_prepare_bf16(t_raw, eps=EPS64):
 
 def corr_fwd_bf16(theta, phi, blab, temperature, h, w, want_small=False, want_argmax=False, want_up=True):
     """bf16 candidate filter + exact fp32 re-scoring.  theta/phi: (fp32 [B,P,C], bf16 [B,P,C]) pairs from
-    corr_prepare_bf16; blab [B,3,P].  Same outputs as corr_fwd.  Requires temperature <= 1e-4."""
+    corr_prepare_bf16; blab [B,3,P].  Same outputs as corr_fwd.  Requires temperature <= 1e-4.
+    theta of ONE frame against the R exemplars of phi / blab (multi-reference pass): one set of launches per exemplar."""
     lib = _lib.load()
     (tf, tb), (pf, pb) = theta, phi
     for t, nm in ((tf, "theta"), (pf, "phi"), (blab, "blab")):
         _need(t, nm)
-    B, P, C = tf.shape
-    assert P == h * w
+    Bt, P, C = tf.shape
+    R = pf.shape[0]
+    refs = Bt == 1 and R > 1
+    B = R if refs else Bt
+    assert P == h * w and (refs or R == Bt) and blab.shape[0] == B
     dev = tf.device
     y_up = sim_up = y_small = sim_small = amax = None
     if want_up:
@@ -803,10 +854,19 @@ def corr_fwd_bf16(theta, phi, blab, temperature, h, w, want_small=False, want_ar
         sim_small = torch.empty((B, 1, h, w), device=dev, dtype=torch.float32)
     if want_argmax:
         amax = torch.empty((B, P), device=dev, dtype=torch.int32)
-    ws = _workspace(dev, lib.dvc_corr_bf16_workspace_bytes(B, P), "corr_bf16")
-    rc = lib.dvc_corr_fwd_bf16(ctypes.c_void_p(tb.data_ptr()), ctypes.c_void_p(pb.data_ptr()), _p(tf), _p(pf),
-                               _p(blab), float(temperature), B, C, h, w, _p(y_small), _p(sim_small), _p(y_up),
-                               _p(sim_up), None if amax is None else ctypes.c_void_p(amax.data_ptr()),
-                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
-    _lib.check(rc, "dvc_corr_fwd_bf16")
+    ws = _workspace(dev, lib.dvc_corr_bf16_workspace_bytes(1 if refs else B, P), "corr_bf16")
+
+    def call(tf_, tb_, pf_, pb_, bl, nb, sl):
+        o = [None if t is None else t[sl] for t in (y_small, sim_small, y_up, sim_up)]
+        rc = lib.dvc_corr_fwd_bf16(ctypes.c_void_p(tb_.data_ptr()), ctypes.c_void_p(pb_.data_ptr()), _p(tf_), _p(pf_),
+                                   _p(bl), float(temperature), nb, C, h, w, _p(o[0]), _p(o[1]), _p(o[2]),
+                                   _p(o[3]), None if amax is None else ctypes.c_void_p(amax[sl].data_ptr()),
+                                   ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+        _lib.check(rc, "dvc_corr_fwd_bf16")
+
+    if refs:
+        for r in range(R):
+            call(tf, tb, pf[r:r + 1], pb[r:r + 1], blab[r:r + 1], 1, slice(r, r + 1))
+    else:
+        call(tf, tb, pf, pb, blab, B, slice(0, B))
     return dict(y_up=y_up, sim_up=sim_up, y_small=y_small, sim_small=sim_small, argmax=amax)

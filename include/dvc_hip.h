@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 11
+#define DVC_ABI_VERSION 12
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -95,6 +95,13 @@ typedef struct DvcConvDesc {
  * sums [split][N][Cout][OH*OW] in the workspace instead of launching the reduce — bias, activation and `y` are then NOT applied /
  * written; the consumer sums them (dvc_instnorm_apply_partials).  No effect when the layer is not split. */
 #define DVC_CONV_DEFER_REDUCE 1
+/* dvc_conv2d_winograd / _pool / _dual / _split: plan the launch for the WHOLE batch (workgroups of all N images fill the chip
+ * together, so layers that would be split over input channels for one image need a smaller split or none) instead of per
+ * image.  Default (bit clear): the plan is that of a single image and a batch of N is bit-identical to N single-image calls
+ * (train.py:402 calls the path with B = 16).  With the bit set the result is deterministic per (layer, N) but the fp32
+ * summation order over input channels — hence the last-place rounding — depends on N.  Used where N images MUST run together
+ * anyway: the R references of one clip (/root/reference/test.py:169-181), whose ColorVidNet recurrences advance in lock step. */
+#define DVC_CONV_BATCH_PLAN 2
 
 /* Output spatial size implied by a descriptor. */
 int dvc_conv2d_out_hw(const DvcConvDesc* d, int32_t* OH, int32_t* OW);
@@ -239,7 +246,9 @@ int dvc_lab2rgb(const float* lab, int32_t N, int32_t HW, float l_offset, float* 
  * is channel 0 of a Lab tensor).  IA_last_lab arrives as its two parts, so that the clip loop never materialises
  * test.py:96's cat((IA_l, ab_predict)) between frames: last_l = luminance plane of the previous frame, last_ab = the
  * previous [N][2][HW] prediction (batch strides 0 = HW / 2 HW); for an existing Lab tensor pass (lab, 3 HW, lab + HW, 3 HW).
- * warped_lab: [N][3][HW] (channels 1, 2 are read); sim: [N][1][HW]. */
+ * warped_lab: [N][3][HW] (channels 1, 2 are read); sim: [N][1][HW].
+ * A NEGATIVE batch stride means "the same plane for every image" (stride 0): one frame against the R references of a clip
+ * (/root/reference/test.py:169-181), whose R ColorVidNet inputs share the frame's luminance. */
 int dvc_pack_color_input(const float* IA_l, int64_t ia_batch_stride, const float* warped_lab, const float* sim,
                          const float* last_l, int64_t last_l_batch_stride, const float* last_ab,
                          int64_t last_ab_batch_stride, int32_t N, int32_t HW, float* out7, dvcStream stream);

@@ -28,16 +28,20 @@ def oracle_exemplar(sd, IB):
         return O.corr_project(sd[1], "phi", O.warp_features(sd[1], *nB))
 
 
-def oracle_front(sd, IB, phi, frame, T):
+def oracle_front(sd, IB, phi, frame, T, keep_theta=False):
     """Front end of one frame through the oracle (O.warp_color's op sequence): the 1/4-resolution warped colours and
-    similarity map, the arg-max and the top-1/top-2 gap of every query row."""
+    similarity map, the arg-max and the top-1/top-2 gap of every query row (keep_theta: also theta, for the admissibility
+    check of matched_oracle_chunk)."""
     with torch.no_grad():
         fA = O.vgg19_forward(sd[0], O.gray2rgb_batch(frame[:, 0:1]), O.VGG_OUT, preprocess=True)
         nA = [O.feature_normalize(t) for t in fA[1:]]
         theta = O.corr_project(sd[1], "theta", O.warp_features(sd[1], *nA))
         y, sim, f = O.correlate(theta, phi, IB, T)
         top2 = torch.topk(f, 2, dim=-1)[0]
-        return dict(y_small=y, sim_small=sim, argmax=f.argmax(-1)[0], gap=(top2[0, :, 0] - top2[0, :, 1]))
+        out = dict(y_small=y, sim_small=sim, argmax=f.argmax(-1)[0], gap=(top2[0, :, 0] - top2[0, :, 1]))
+        if keep_theta:
+            out["theta"] = theta
+        return out
 
 
 def hip_front(vgg, warp, cc, frame_dev, T):
@@ -50,27 +54,44 @@ def hip_front(vgg, warp, cc, frame_dev, T):
     return dict(argmax=tp["argmax"][0].cpu().long(), sim_small=tp["sim_small"].cpu(), y_small=tp["y_small"].cpu(), y_up=y_up)
 
 
-def matched_oracle_chunk(sd, IB, frames, fronts, hip_fronts):
+def matched_oracle_chunk(sd, IB, frames, fronts, hip_fronts, phi=None):
     """The oracle's recurrence over one chunk (I_last = 0 at its first frame) with the HIP path's tie-breaks.
-    Returns (list of ab, list of per-frame dicts: flipped rows, their oracle gaps, similarity error)."""
+    A row is "flipped" when the HIP path's warped colour differs from the oracle's by more than 1e-4 — another exemplar position
+    at a near-tie, or (flat image regions: exactly duplicated exemplar features) another split of the weight among tied
+    positions; on those rows the HIP path's own colour is handed to the oracle's ColorVidNet.  With `phi` and fronts that kept
+    theta the substitution is checked to be ADMISSIBLE: the HIP colour must lie inside the range of the pooled colours of the
+    keys whose float64 affinity is within 1e-5 of the row maximum (`inadmissible` counts the rows where it does not).
+    Returns (list of ab, list of per-frame dicts: flipped rows, their oracle gaps, similarity error, ...)."""
     blab = F.avg_pool2d(IB, 4).view(3, -1)
     h, w = IB.shape[2] // 4, IB.shape[3] // 4
     outs, stats = [], []
     last = torch.zeros_like(frames[0])
     with torch.no_grad():
         for fr, fo, fh in zip(frames, fronts, hip_fronts):
-            flipped = fh["argmax"] != fo["argmax"]
-            rows = flipped.nonzero().flatten()
             y = fo["y_small"].clone().view(3, -1)
-            y[:, rows] = blab[:, fh["argmax"][rows]]
+            yh = fh["y_small"].view(3, -1)
+            flipped = (yh - y).abs().max(0)[0] > 1e-4
+            rows = flipped.nonzero().flatten()
+            inadmissible = 0
+            if rows.numel() and phi is not None and "theta" in fo:
+                f64 = fo["theta"][0].double()[:, rows].t() @ phi[0].double()                   # [n_flipped, P]
+                near = f64 >= f64.max(-1, keepdim=True)[0] - 1e-5
+                for c in range(3):
+                    lo = torch.where(near, blab[c].double()[None], torch.tensor(float("inf"), dtype=torch.float64)).min(-1)[0]
+                    hi = torch.where(near, blab[c].double()[None], torch.tensor(float("-inf"), dtype=torch.float64)).max(-1)[0]
+                    bad = (yh[c, rows].double() < lo - 1e-4) | (yh[c, rows].double() > hi + 1e-4)
+                    inadmissible = max(inadmissible, int(bad.sum()))
+            y[:, rows] = yh[:, rows]
             y_up = F.interpolate(y.view(1, 3, h, w), scale_factor=4, mode="nearest")
             sim_up = F.interpolate(fo["sim_small"], scale_factor=4, mode="nearest")
             ab = O.colorvidnet_forward(sd[2], torch.cat((fr[:, 0:1], y_up[:, 1:3], sim_up, last), dim=1))
             last = torch.cat((fr[:, 0:1], ab), dim=1)
             outs.append(ab)
+            agree = ~flipped
             stats.append(dict(flipped=int(flipped.sum()), gaps=fo["gap"][flipped].tolist(), min_gap=fo["gap"].min().item(),
-                              near_ties=int((fo["gap"] < 1e-5).sum()),
+                              near_ties=int((fo["gap"] < 1e-5).sum()), exact_ties=int((fo["gap"] == 0).sum()),
+                              argmax_differs=int((fh["argmax"] != fo["argmax"]).sum()), inadmissible=inadmissible,
                               sim_err=(fh["sim_small"] - fo["sim_small"]).abs().max().item(),
-                              # one-hot colours, flipped rows included: the HIP y is the pooled colour of ITS position
-                              y_err=(fh["y_small"].view(3, -1) - y).abs().max().item()))
+                              # warped colours on the agreeing rows (one-hot rows: pooled means of 16 values ~100)
+                              y_err=(yh - fo["y_small"].view(3, -1))[:, agree].abs().max().item() if agree.any() else 0.0))
     return outs, stats

@@ -209,3 +209,37 @@ def test_winograd_plan_is_a_pure_function_of_the_layer_not_of_the_batch():
     bad = _lib.DvcConvDesc(1, 3, 54, 96, 64, 3, 1, 1, 1, 0, 1, 1, 1, 0.0, 0, -1, 0, 0, 0, 0, 0)
     assert lib.dvc_conv2d_winograd_split(ctypes.byref(bad), ws, ctypes.byref(sp), ctypes.byref(ipl)) != 0
     assert b"Cin" in lib.dvc_last_error()
+
+
+def test_batch_plan_flag_trades_the_split_for_the_batch():
+    """DVC_CONV_BATCH_PLAN (include/dvc_hip.h): the plan of the WHOLE batch — the multi-reference pass runs R ColorVidNet
+    recurrences in lock step, so the R images' workgroups fill the chip together and an under-filled layer needs a smaller
+    split over input channels (or none).  Host logic: the flag never changes a single image's plan, never raises the split,
+    lowers it on the network's under-filled layers at R = 4, and `ops.batch_plan` sets it only while active."""
+    import ctypes
+    from dvc_amd import _lib, ops
+    lib = _lib.load()
+    ws = 64 << 20
+
+    def split(N, ci, co, H, W, dil, flags):
+        d = _lib.DvcConvDesc(N, ci, H, W, co, 3, 1, dil, dil, 0, 1, 1, 1, 0.0, 0, -1, 0, 0, 0, 0, flags)
+        sp, ipl = ctypes.c_int32(0), ctypes.c_int32(0)
+        assert lib.dvc_conv2d_winograd_split(ctypes.byref(d), ws, ctypes.byref(sp), ctypes.byref(ipl)) == 0, lib.dvc_last_error()
+        return sp.value
+
+    lowered = 0
+    for (ci, co, H, W, dil) in [(256, 256, 54, 96, 1), (512, 512, 27, 48, 1), (512, 512, 27, 48, 2), (128, 128, 216, 384, 1),
+                                (256, 256, 108, 192, 1), (128, 256, 54, 96, 1)]:
+        base = split(1, ci, co, H, W, dil, 0)
+        assert split(1, ci, co, H, W, dil, ops.BATCH_PLAN) == base
+        assert split(4, ci, co, H, W, dil, 0) == base
+        s4 = split(4, ci, co, H, W, dil, ops.BATCH_PLAN)
+        assert 1 <= s4 <= base, (ci, co, H, W, base, s4)
+        lowered += s4 < base
+    assert lowered >= 2
+    assert ops._plan_flags(4) == 0
+    with ops.batch_plan(True):
+        assert ops._plan_flags(4) == ops.BATCH_PLAN and ops._plan_flags(1) == 0
+        with ops.batch_plan(False):
+            assert ops._plan_flags(4) == 0
+    assert not ops.batch_plan_enabled()

@@ -833,8 +833,7 @@ def test_corr_bf16_exact_ties_split_equally(ops, h, w, k, layout, T):
     if layout == "spread":
         th, ph, lab_map, dups, qs = _tie_case(h, w, 2, "ranges", g)
         j0 = dups[0]
-        extra = [(j0 + 37 + 71 * i) % P for i in range(k - 1)]
-        dups = [j0] + extra
+        dups = dups + [(j0 + 37 + 71 * i) % P for i in range(k - 2)]        # (the two copies _tie_case made + k - 2 more)
         assert len(set(dups)) == k
         ph[:, :, dups] = ph[:, :, j0:j0 + 1]
     else:

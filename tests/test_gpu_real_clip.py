@@ -1,0 +1,194 @@
+"""Real content through the path and the CLI (task 5): an excerpt of the reference's OWN sample inputs
+(tests/golden/real_v32, written by tools/make_real_clip_fixture.py from /root/reference/sample_videos/{clips,ref}/v32: a
+monochrome film scan with 37 % of its pixels at or near black, and the four colour references test.py:169-181 loops over)
+and synthetic frames with the pathologies real footage has (letter-box bars, flat regions, clipped highlights) against the
+oracle.
+
+The networks carry the synthetic weights (the released checkpoints are not in the tree; VGG19 / WarpNet plain random,
+ColorVidNet the well-conditioned set), the comparison is the tie-break-matched oracle recurrence of tests/c3_common.py with
+its admissibility check: on a row where the two paths' warped colours differ, the oracle's top-1/top-2 gap must be < 1e-5
+and the HIP colour must lie inside the colour range of the keys within 1e-5 of the row maximum.  Near-tie, exact-tie and
+flipped rows are counted per frame in gpurun_out/test_report.txt."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "test_report.txt")
+FIX = os.path.join(ROOT, "tests", "golden", "real_v32")
+NORTH_STAR_TOL = 1e-3
+
+
+def report(line):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(line + "\n")
+
+
+def _oracle_threads():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(32, avail)))
+
+
+def _nets():
+    from dvc_amd import synth
+    from models.ColorVidNet import ColorVidNet
+    from models.NonlocalNet import VGG19_pytorch, WarpNet
+    sd = (synth.vgg19_state_dict(0), synth.warpnet_state_dict(0), synth.colorvidnet_state_dict(0, contractive=True))
+    with contextlib.redirect_stdout(io.StringIO()):
+        nets = (VGG19_pytorch(), WarpNet(1), ColorVidNet(7))
+    for m, s in zip(nets, sd):
+        m.load_state_dict(s)
+        m.eval().cuda()
+    return nets, sd
+
+
+def _fixture_frames(n):
+    from PIL import Image
+    names = sorted(os.listdir(os.path.join(FIX, "clip")), key=lambda f: int("".join(filter(str.isdigit, f) or -1)))
+    return names[:n], [np.ascontiguousarray(np.array(Image.open(os.path.join(FIX, "clip", nm)).convert("RGB"))) for nm in names[:n]]
+
+
+def _fixture_ref(name):
+    from PIL import Image
+    return np.ascontiguousarray(np.array(Image.open(os.path.join(FIX, "ref", name)).convert("RGB")))
+
+
+def _check_chunk(tag, got, want, stats, allow_inadmissible=0):
+    worst = 0.0
+    for i, (g, w_, st) in enumerate(zip(got, want, stats)):
+        d = (g.cpu() - w_).abs().max().item()
+        worst = max(worst, d)
+        report(f"{tag} frame {i}: oracle rows with gap<1e-5: {st['near_ties']} (exact ties: {st['exact_ties']}, min gap {st['min_gap']:.2e}); "
+               f"arg-max differs on {st['argmax_differs']} rows, warped colour differs on {st['flipped']} rows (gaps {st['gaps'][:6]}), "
+               f"inadmissible {st['inadmissible']}; sim_err={st['sim_err']:.2e}; ab vs tie-break-matched oracle max={d:.2e}")
+        assert all(gp < 1e-5 for gp in st["gaps"]), (tag, i, st)
+        assert st["inadmissible"] <= allow_inadmissible, (tag, i, st)
+        assert st["sim_err"] < 1e-5 and st["y_err"] <= 1e-4, (tag, i, st)
+        assert d <= NORTH_STAR_TOL, (tag, i, d)
+    return worst
+
+
+@pytest.mark.parametrize("ref_name", ["01.png", "03.png"])
+def test_real_frames_network_path_against_the_oracle_216x384(ref_name):
+    """The reference's sample clip v32 (first 6 frames of the excerpt) against one of its references at the network resolution
+    test.py uses (frames ingested to 432x768 by the ORACLE's CenterPad / RGB2Lab so that both paths start from identical Lab
+    tensors, x0.5 -> 216x384): ClipColorizer.clip (pipelined) against the tie-break-matched oracle recurrence, every frame
+    within the north-star 1e-3."""
+    import c3_common as C
+    from dvc_amd.frame import ClipColorizer
+    from oracle import ingest_oracle, tail_oracle
+    T, size = 1e-10, (432, 768)
+    _oracle_threads()
+    (vgg, warp, col), sd = _nets()
+    _, rgb = _fixture_frames(6)
+    half = lambda t: torch.from_numpy(tail_oracle.downsample_half(t.numpy()))            # noqa: E731  (test.py:58,71)
+    frames = [half(torch.from_numpy(ingest_oracle.frame_ingest(f, size))[None]) for f in rgb]
+    IB = half(torch.from_numpy(ingest_oracle.frame_ingest(_fixture_ref(ref_name), size))[None])
+    assert tuple(frames[0].shape) == (1, 3, 216, 384)
+    cc = ClipColorizer(vgg, warp, col, temperature=T)
+    cc.set_exemplar(IB.cuda())
+    dev = [f.cuda() for f in frames]
+    got = cc.clip(dev, lookahead=2)
+    torch.cuda.synchronize()
+    hip_fronts = [C.hip_front(vgg, warp, cc, f, T) for f in dev]
+    phi = C.oracle_exemplar(sd, IB)
+    fronts = [C.oracle_front(sd, IB, phi, f, T, keep_theta=True) for f in frames]
+    want, stats = C.matched_oracle_chunk(sd, IB, frames, fronts, hip_fronts, phi=phi)
+    worst = _check_chunk(f"real clip v32 vs reference {ref_name} 216x384", got, want, stats)
+    dark = float(np.mean([(f <= 5).mean() for f in rgb]))
+    report(f"real clip v32 vs reference {ref_name}: 6 frames, {dark * 100:.0f} % of the input pixels <= 5; worst ab error {worst:.2e}; "
+           f"|ab| max {max(w_.abs().max().item() for w_ in want):.1f}")
+    assert max(w_.abs().max().item() for w_ in want) > 1.0
+
+
+def test_letter_box_bars_flat_regions_and_clipped_highlights_216x384():
+    """Synthetic frames with what real footage has and the smooth synth_lab fields lack: letter-box bars (exactly black rows top
+    and bottom), a perfectly flat rectangle and a clipped highlight, in the frames AND in the exemplar.  (Measured with the
+    oracle: such regions do NOT produce exact ties in the correlation — the features' receptive field (VGG19 relu5_2 + WarpNet's
+    heads and three residual blocks + InstanceNorm) spans the frame, so no two positions see identical content; the rows with
+    a top-1/top-2 gap below 1e-5 stay a handful per frame, as for the smooth fields.  Exact duplicates with DIFFERENT colours are
+    a kernel-level case: tests/test_gpu_ops.py::test_corr_exact_ties_split_equally.)  Every frame within 1e-3 of the
+    tie-break-matched oracle recurrence; constant planes go through InstanceNorm / the Lab->RGB clamps on both sides."""
+    import c3_common as C
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    H, W, T = 216, 384, 1e-10
+    _oracle_threads()
+    (vgg, warp, col), sd = _nets()
+
+    def pathological(seed):
+        x = synth.synth_lab(seed, H, W).clone()
+        x[:, 0, :28] = -50.0; x[:, 1:, :28] = 0.0                      # letter-box bars: L = 0 (centred -50), ab = 0
+        x[:, 0, -28:] = -50.0; x[:, 1:, -28:] = 0.0
+        x[:, 0, 80:136, 40:136] = 10.0; x[:, 1, 80:136, 40:136] = 20.0; x[:, 2, 80:136, 40:136] = -15.0     # a flat patch
+        x[:, 0, 60:120, 250:330] = x[:, 0, 60:120, 250:330].clamp(max=30.0).add(100).clamp(max=50.0)         # clipped highlight (L = 100)
+        return x.contiguous()
+
+    IB = pathological(synth.EXEMPLAR_SEED)
+    frames = [pathological(synth.FRAME_SEED0 + i) for i in range(4)]
+    cc = ClipColorizer(vgg, warp, col, temperature=T)
+    cc.set_exemplar(IB.cuda())
+    dev = [f.cuda() for f in frames]
+    got = cc.clip(dev, lookahead=2)
+    torch.cuda.synchronize()
+    hip_fronts = [C.hip_front(vgg, warp, cc, f, T) for f in dev]
+    phi = C.oracle_exemplar(sd, IB)
+    fronts = [C.oracle_front(sd, IB, phi, f, T, keep_theta=True) for f in frames]
+    want, stats = C.matched_oracle_chunk(sd, IB, frames, fronts, hip_fronts, phi=phi)
+    worst = _check_chunk("letter-box / flat-region frames 216x384", got, want, stats)
+    report(f"letter-box / flat-region frames: exact-tie rows per frame {[st['exact_ties'] for st in stats]}, near-tie rows "
+           f"{[st['near_ties'] for st in stats]}, worst ab error {worst:.2e}")
+
+
+def test_cli_on_the_reference_sample_clip_against_the_composed_oracle(tmp_path, monkeypatch):
+    """cli.colorize_video — PIL decode, device ingest (anti-aliased 960x540 -> 768x432 CenterPad, RGB2Lab), networks at
+    216x384, x2 bilinear, WLS filter, Lab -> RGB8 — on 4 frames of the sample clip with reference 01, against
+    oracle/video_oracle.colorize_video on the same arrays.  The two chains do not start from identical Lab tensors (the device
+    ingest agrees with the oracle's to one 8-bit level on < 0.05 % of the values, tests/test_ingest.py), so this is the loose,
+    whole-chain statement next to the strict one above: at least 99.5 % of every saved frame's values within one 8-bit level,
+    mean absolute difference below 0.05 levels; frames whose oracle correlation has no row below fp32 resolution (gap >= 2e-6)
+    within one level on 99.9 %."""
+    from PIL import Image
+    from dvc_amd import cli
+    from oracle import video_oracle
+    (vgg, warp, col), sd = _nets()
+    names, rgb = _fixture_frames(4)
+    clip = tmp_path / "clips" / "v32"
+    os.makedirs(clip)
+    for nm, a in zip(names, rgb):
+        Image.fromarray(a).save(str(clip / nm))
+    ref = _fixture_ref("01.png")
+    Image.fromarray(ref).save(str(tmp_path / "ref01.png"))
+    saved = []
+    real_save = cli.save_frames
+    monkeypatch.setattr(cli, "save_frames", lambda image, folder, index=None, image_name=None:
+                        (saved.append(np.array(image)), real_save(image, folder, index, image_name))[1])
+    opt = cli.build_parser().parse_args([])
+    opt.batch_frames = 3
+    with contextlib.redirect_stdout(io.StringIO()):
+        cli.colorize_video(opt, str(clip) + "/", str(tmp_path / "ref01.png"), str(tmp_path / "out"), warp, col, vgg)
+    _oracle_threads()
+    taps = {}
+    want = video_oracle.colorize_video(rgb, ref, opt.image_size, *sd, taps=taps)
+    assert len(saved) == len(want) == 4
+    lines = []
+    for i, (a, w_) in enumerate(zip(saved, want)):
+        assert a.shape == w_.shape == (432, 768, 3)
+        d = np.abs(a.astype(np.int16) - w_.astype(np.int16))
+        within1, mean = float((d <= 1).mean()), float(d.mean())
+        lines.append(f"frame{i}: values within one level {within1 * 100:.3f} %, exactly equal {float((d == 0).mean()) * 100:.3f} %, max {int(d.max())}, "
+                     f"mean {mean:.4f} (oracle min gap {taps['min_gap'][i]:.1e})")
+        assert within1 >= 0.995 and mean <= 0.05, (i, within1, mean)
+        if taps["min_gap"][i] >= 2e-6:
+            assert within1 >= 0.999, (i, within1)
+    report("cli.colorize_video on the reference's sample clip v32 / ref 01 vs the composed oracle: " + "; ".join(lines))

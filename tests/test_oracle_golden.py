@@ -176,6 +176,9 @@ def test_c3_helper_recurrence_is_colorize_clip_when_nothing_flips():
         assert torch.equal(a, b) and st["flipped"] == 0 and st["y_err"] == 0.0
     other = [dict(argmax=f["argmax"].clone(), sim_small=f["sim_small"], y_small=f["y_small"]) for f in fronts]
     other[1]["argmax"][7] = (other[1]["argmax"][7] + 11) % (H // 4 * W // 4)
+    blab = torch.nn.functional.avg_pool2d(IB, 4).view(3, -1)
+    other[1]["y_small"] = fronts[1]["y_small"].clone()
+    other[1]["y_small"].view(3, -1)[:, 7] = blab[:, other[1]["argmax"][7]]            # (the other path's colour at its position)
     got2, stats2 = C.matched_oracle_chunk(sd, IB, frames, fronts, other)
     assert torch.equal(got2[0], want[0]) and stats2[1]["flipped"] == 1
     assert not torch.equal(got2[1], want[1]) and not torch.equal(got2[2], want[2])     # the flip propagates along the recurrence
