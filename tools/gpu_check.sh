@@ -42,3 +42,13 @@ if [[ $what == pmc || $what == all2 ]]; then
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU --output-format csv -d gpurun_out/pmc4 -o p -- python tools/prof_kernels.py > gpurun_out/pmc4.log 2>&1; echo "pmc4 rc=$?"
   ls gpurun_out/pmc*/ ; tail -n 3 gpurun_out/pmc1.log; tail -n 3 gpurun_out/pmc4.log
 fi
+if [[ $what == pmcr ]]; then
+  # the same counters on ColorVidNet's layer shapes at batch 4 under the batch-aware plan (multi-reference pass)
+  rm -rf gpurun_out/pmcr*
+  export DVC_PROF_R=4
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pmcr1 -o p -- python tools/prof_kernels.py > gpurun_out/pmcr1.log 2>&1; echo "pmcr1 rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcr2 -o p -- python tools/prof_kernels.py > gpurun_out/pmcr2.log 2>&1; echo "pmcr2 rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcr3 -o p -- python tools/prof_kernels.py > gpurun_out/pmcr3.log 2>&1; echo "pmcr3 rc=$?"
+  unset DVC_PROF_R
+  tail -n 3 gpurun_out/pmcr1.log
+fi

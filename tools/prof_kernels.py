@@ -11,6 +11,22 @@ from dvc_amd import ops  # noqa: E402
 
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(1)
+R = int(os.environ.get("DVC_PROF_R", "1"))
+if R > 1:
+    # the multi-reference pass (ClipColorizer.set_exemplars): ColorVidNet's layer shapes at batch R under the batch-aware launch
+    # plan (DVC_CONV_BATCH_PLAN) — what r04's PMC pass reports next to the single-image launches
+    with ops.batch_plan(True):
+        for (ci, co, H, W, dil, up) in [(256, 256, 54, 96, 1, 1), (512, 512, 27, 48, 1, 1), (512, 512, 27, 48, 2, 1),
+                                        (128, 128, 108, 192, 1, 1), (64, 64, 216, 384, 1, 1), (128, 128, 216, 384, 1, 1),
+                                        (128, 256, 54, 96, 1, 1), (256, 512, 27, 48, 1, 1)]:
+            x = torch.randn(R, ci, H, W, device=dev)
+            u = ops.pack_winograd_weight(torch.randn(co, ci, 3, 3, device=dev) * 0.05)
+            b = torch.randn(co, device=dev)
+            for _ in range(3):
+                ops.conv2d_winograd(x, u, b, dil=dil, in_up=up, act=1)
+    torch.cuda.synchronize()
+    print("done (batch %d, batch plan)" % R)
+    sys.exit(0)
 h, w = 54, 96
 P = h * w
 th = ops.corr_prepare(torch.randn(1, 256, P, generator=g).to(dev))

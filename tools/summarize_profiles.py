@@ -30,39 +30,53 @@ def load(path):
     return list(csv.DictReader(open(path))) if os.path.exists(path) else []
 
 
-dur = collections.defaultdict(list)
-for r in load(os.path.join(G, "pmc1", "p_kernel_trace.csv")):
-    dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for pm in ("pmc1", "pmc2", "pmc3", "pmc4"):
-    for r in load(os.path.join(G, pm, "p_counter_collection.csv")):
-        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-lines = ["# PMC summary (" + tag + ")", "",
-         "Source: `rocprofv3 --kernel-trace --pmc ...` in four separate passes over `tools/prof_kernels.py` "
-         "(corr at P=5184, representative conv layers); counters averaged over the launches of each kernel.",
-         "`GRBM_GUI_ACTIVE` is summed over the 8 XCDs (divide by 8 for cycles); `SQ_WAVE_CYCLES`/`SQ_WAIT_*`/"
-         "`SQ_ACTIVE_INST_ANY` count quad-cycles (x4). `FETCH_SIZE`/`WRITE_SIZE` are KiB; per "
-         "MI355X_MICROARCH.md the gfx950 FETCH_SIZE counts 64 B per 128-B request, so read bytes = 2 x FETCH_SIZE.",
-         "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles).", "",
-         "| kernel | us | clock GHz | waves | MFMA util | per-wave kcycles: alive / own-MFMA / active / wait-inst / wait-any | VALU/wave | LDS bank-conflict cyc | HBM read MB (2xFETCH) | HBM write MB |",
-         "|---|---|---|---|---|---|---|---|---|---|"]
-for k, v in agg.items():
-    if "conv_mfma" not in k and "corr_fwd" not in k and "conv_sk_kernel" not in k and "conv_wino" not in k:
-        continue
-    c = {n: sum(x) / len(x) for n, x in v.items()}
-    if "GRBM_GUI_ACTIVE" not in c:
-        continue
-    us = sum(dur[k]) / max(len(dur[k]), 1)
-    cyc = c["GRBM_GUI_ACTIVE"] / 8
-    w = c["SQ_WAVES"]
-    lines.append("| `%s` | %.0f | %.2f | %d | %.1f%% | %.0f / %.0f / %.0f / %.0f / %.0f | %.0f | %.0f | %.1f | %.1f |" % (
-        k.replace("void ", "").replace("(ConvKArgs)", "").replace("(CorrArgs)", "").replace("(ConvSkArgs)", "").replace("(ConvWinoArgs)", ""), us, cyc / us / 1e3, w,
-        100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), c["SQ_WAVE_CYCLES"] * 4 / w / 1e3,
-        c["SQ_VALU_MFMA_BUSY_CYCLES"] / w / 1e3, c["SQ_ACTIVE_INST_ANY"] * 4 / w / 1e3,
-        c["SQ_WAIT_INST_ANY"] * 4 / w / 1e3, c.get("SQ_WAIT_ANY", 0) * 4 / w / 1e3, c.get("SQ_INSTS_VALU", 0) / w,
-        c.get("SQ_LDS_BANK_CONFLICT", 0), 2 * c.get("FETCH_SIZE", 0) / 1024, c.get("WRITE_SIZE", 0) / 1024))
-if len(lines) > 9:
-    open(os.path.join(P, f"{tag}_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
+def table(prefix, title, note):
+    """Markdown table of the derived per-kernel metrics of the passes gpurun_out/<prefix>1..4 (None if the passes are absent)."""
+    dur = collections.defaultdict(list)
+    for r in load(os.path.join(G, prefix + "1", "p_kernel_trace.csv")):
+        dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for pm in (prefix + "1", prefix + "2", prefix + "3", prefix + "4"):
+        for r in load(os.path.join(G, pm, "p_counter_collection.csv")):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    lines = [title, "", note, "",
+             "| kernel | us | clock GHz | waves | MFMA util | per-wave kcycles: alive / own-MFMA / active / wait-inst / wait-any | VALU/wave | LDS bank-conflict cyc | HBM read MB (2xFETCH) | HBM write MB |",
+             "|---|---|---|---|---|---|---|---|---|---|"]
+    n0 = len(lines)
+    for k, v in agg.items():
+        if "conv_mfma" not in k and "corr_fwd" not in k and "conv_sk_kernel" not in k and "conv_wino" not in k:
+            continue
+        c = {n: sum(x) / len(x) for n, x in v.items()}
+        if "GRBM_GUI_ACTIVE" not in c:
+            continue
+        us = sum(dur[k]) / max(len(dur[k]), 1)
+        cyc = c["GRBM_GUI_ACTIVE"] / 8
+        w = c["SQ_WAVES"]
+        lines.append("| `%s` | %.0f | %.2f | %d | %.1f%% | %.0f / %.0f / %.0f / %.0f / %.0f | %.0f | %.0f | %.1f | %.1f |" % (
+            k.replace("void ", "").replace("(ConvKArgs)", "").replace("(CorrArgs)", "").replace("(ConvSkArgs)", "").replace("(ConvWinoArgs)", ""), us, cyc / us / 1e3, w,
+            100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), c["SQ_WAVE_CYCLES"] * 4 / w / 1e3,
+            c["SQ_VALU_MFMA_BUSY_CYCLES"] / w / 1e3, c["SQ_ACTIVE_INST_ANY"] * 4 / w / 1e3,
+            c["SQ_WAIT_INST_ANY"] * 4 / w / 1e3, c.get("SQ_WAIT_ANY", 0) * 4 / w / 1e3, c.get("SQ_INSTS_VALU", 0) / w,
+            c.get("SQ_LDS_BANK_CONFLICT", 0), 2 * c.get("FETCH_SIZE", 0) / 1024, c.get("WRITE_SIZE", 0) / 1024))
+    return (lines if len(lines) > n0 else None), agg
+
+
+lines, agg = table("pmc", "# PMC summary (" + tag + ")",
+                   "Source: `rocprofv3 --kernel-trace --pmc ...` in four separate passes over `tools/prof_kernels.py` "
+                   "(corr at P=5184, representative conv layers); counters averaged over the launches of each kernel.\n"
+                   "`GRBM_GUI_ACTIVE` is summed over the 8 XCDs (divide by 8 for cycles); `SQ_WAVE_CYCLES`/`SQ_WAIT_*`/"
+                   "`SQ_ACTIVE_INST_ANY` count quad-cycles (x4). `FETCH_SIZE`/`WRITE_SIZE` are KiB; per "
+                   "MI355X_MICROARCH.md the gfx950 FETCH_SIZE counts 64 B per 128-B request, so read bytes = 2 x FETCH_SIZE.\n"
+                   "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles).")
+lines_r, _ = table("pmcr", "## The same counters at batch 4 under the batch-aware plan (multi-reference pass)",
+                   "Source: the same passes over `DVC_PROF_R=4 tools/prof_kernels.py`: ColorVidNet's layer shapes with 4 images per "
+                   "launch, planned as a batch (`DVC_CONV_BATCH_PLAN`, ClipColorizer.set_exemplars); a kernel name averages over the "
+                   "layers that share its instantiation.")
+if lines:
+    open(os.path.join(P, f"{tag}_pmc_summary.md"), "w").write("\n".join(lines + ([""] + lines_r if lines_r else [])) + "\n")
+elif lines_r:
+    open(os.path.join(P, f"{tag}_pmc_summary.md"), "w").write("\n".join(["# PMC summary (" + tag + ")", ""] + lines_r) + "\n")
+lines = (lines or []) + (lines_r or [])
 # the correlation kernel's HBM traffic per launch, the number bench.py's roofline.traffic cites (file + hash)
 for k, v in agg.items():
     if "corr_fwd_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
