@@ -489,26 +489,39 @@ def main():
         bl = bl4.view(1, 3, -1)
         # warm-up: the first milliseconds after the clip run at a lower clock (measured: 148 us vs 129 us per launch once the
         # correlation alone has run for ~10 ms — tools/corr_ab_probe.py times round-robin for the same reason)
-        for _ in range(100 if P <= 6000 else 10):
-            ops.corr_fwd(th, ph, bl, 1e-10, H // 4, W // 4)
+        # What is timed is what the clip driver launches for this stage: since r04 the fused kernel alone — the merge of its
+        # per-workgroup partial states runs inside the consumer's launch (ops.pack_color_input -> dvc_corr_merge_pack, which
+        # replaces the separate merge AND pack launches) — unless DVC_FOLD_MERGE=0 / the bf16 path; the stand-alone form
+        # (kernel + corr_merge_kernel, what r01-r03 timed) is measured right after and reported next to it.
+        folded = ops.fold_merge() and args.corr == "fp32"
         reps = 50 if P <= 6000 else 10
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()                      # ops launch on torch's current stream, so these events see them
-        for _ in range(reps):
-            ops.corr_fwd(th, ph, bl, 1e-10, H // 4, W // 4)
-        e1.record()
-        torch.cuda.synchronize()
-        t_corr = e0.elapsed_time(e1) * 1e-3 / reps      # fused kernel + its (tiny) merge kernel
+
+        def time_corr(defer):
+            for _ in range(100 if P <= 6000 else 10):
+                ops.corr_fwd(th, ph, bl, 1e-10, H // 4, W // 4, defer_merge=defer)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                      # ops launch on torch's current stream, so these events see them
+            for _ in range(reps):
+                ops.corr_fwd(th, ph, bl, 1e-10, H // 4, W // 4, defer_merge=defer)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+        t_standalone = time_corr(False)      # fused kernel + its merge kernel
+        t_corr = time_corr(True) if folded else t_standalone
         achieved = CORR_FLOPS / t_corr / 1e12
         traffic, traffic_src = corr_traffic() if (H, W) == (216, 384) else (None, {"kind": "not measured at this size"})
         exec_flops, direct_flops, n_convs = executed_matrix_flops(cc, frames[Wm], torch.zeros_like(frames[Wm]))
         exec_tflops = exec_flops * fps / n_gpus / 1e12
-        roof = {"kernel": "corr_fwd_kernel (+corr_merge_kernel)", "bound": "mfma",
+        roof = {"kernel": "corr_fwd_kernel (merge folded into the consumer's launch, dvc_corr_merge_pack)" if folded else
+                "corr_fwd_kernel (+corr_merge_kernel)", "bound": "mfma",
                 "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "operands": "theta of the first timed frame, phi / pooled Lab of the exemplar (the clip's own features)",
                 "avg_launch_us": round(t_corr * 1e6, 2),
+                "with_standalone_merge": {"avg_launch_us": round(t_standalone * 1e6, 2),
+                                          "frac": round(CORR_FLOPS / t_standalone / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                          "note": "corr_fwd_kernel + corr_merge_kernel as two launches: the form r01-r03 timed"},
                 "hbm_view": {"achieved": round(CORR_BYTES / t_corr / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": round(CORR_BYTES / t_corr / 1e9 / PEAK_HBM_GBS, 5),
                              "note": "fused kernel never materialises the PxP affinity; compulsory bytes "

@@ -560,13 +560,23 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_kernel(CorrArgs a) {
 // the groups are combined through LDS in a fixed order (deterministic).
 #define CORR_MQ 32
 #define CORR_MG 8
+// The consumer's form (dvc_corr_merge_pack): `out7` != NULL makes this launch ALSO the cat() of models/FrameColor.py:63-64 — the
+// merged warped ab and similarity go straight into channels 1..3 of ColorVidNet's 7-channel input (x4 nearest), and the
+// workgroup copies the 4x4 pixel blocks of its 32 queries of the four planes that are pure data movement (current L,
+// previous L, previous ab) — so neither the warped Lab / similarity maps nor a separate pack launch exist.
+struct CorrPackArgs {
+    float* out7;             // [7][16 P] or NULL
+    const float* IA_l;       // [16 P]
+    const float* last_l;     // [16 P]
+    const float* last_ab;    // [2][16 P]
+};
 __global__ __launch_bounds__(256) void corr_merge_kernel(const float* __restrict__ part, int nslot, int P,
                                                          int nqb, int ntiles, long U, long G, float mscale,
                                                          int h, int w, float* __restrict__ y_small,
                                                          float* __restrict__ sim_small,
                                                          float* __restrict__ y_up,
                                                          float* __restrict__ sim_up,
-                                                         int* __restrict__ argmax) {
+                                                         int* __restrict__ argmax, CorrPackArgs pk) {
     __shared__ float sh[CORR_MG][7][CORR_MQ];
     const int qx_ = threadIdx.x & (CORR_MQ - 1), g = threadIdx.x / CORR_MQ;
     const int q = blockIdx.x * CORR_MQ + qx_;
@@ -612,6 +622,23 @@ __global__ __launch_bounds__(256) void corr_merge_kernel(const float* __restrict
     sh[g][3][qx_] = Y1;
     sh[g][4][qx_] = Y2;
     __syncthreads();
+    const long W4 = 4L * w, HW16 = 16L * P;
+    if (pk.out7) {
+        // the four copied planes: 4 planes x 32 queries x 4 rows = 512 float4 pieces, two per thread
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = threadIdx.x + it * 256;
+            const int plane = item >> 7, qi = (item >> 2) & 31, dy = item & 3;
+            const int qq = blockIdx.x * CORR_MQ + qi;
+            if (qq < P) {
+                const int qy_ = qq / w, qx2 = qq - qy_ * w;
+                const long off = (4L * qy_ + dy) * W4 + 4L * qx2;
+                const float* src = plane == 0 ? pk.IA_l : plane == 1 ? pk.last_l : pk.last_ab + (plane - 2) * HW16;
+                float* dst = pk.out7 + (plane == 0 ? 0L : (long)(plane + 3) * HW16);
+                *reinterpret_cast<float4*>(dst + off) = *reinterpret_cast<const float4*>(src + off);
+            }
+        }
+    }
     if (g != 0 || !ok) return;
     L = Y0 = Y1 = Y2 = 0.f;
 #pragma unroll
@@ -636,7 +663,15 @@ __global__ __launch_bounds__(256) void corr_merge_kernel(const float* __restrict
     if (sim_small) sim_small[(long)b * P + q] = F;
     if (argmax) argmax[(long)b * P + q] = A;
     const int qy = q / w, qx = q - qy * w;
-    const long W4 = 4L * w, HW16 = 16L * P;
+    if (pk.out7) {
+        const float v3[3] = {yv[1], yv[2], F};
+        for (int c = 0; c < 3; ++c) {
+            float4 v = make_float4(v3[c], v3[c], v3[c], v3[c]);
+            float* o = pk.out7 + (long)(c + 1) * HW16 + (4L * qy) * W4 + 4L * qx;
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) *reinterpret_cast<float4*>(o + dy * W4) = v;
+        }
+    }
     if (y_up) {
         for (int c = 0; c < 3; ++c) {
             float4 v = make_float4(yv[c], yv[c], yv[c], yv[c]);
@@ -775,15 +810,39 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
         launch(false);
         DVC_CHECK_LAUNCH("dvc_corr_fwd(pass1)");
         hipLaunchKernelGGL(corr_merge_kernel, mgrid, dim3(256), 0, s, a.part, a.nslot, P, pl.nqb, pl.ntiles, pl.U,
-                           pl.G, mscale, h, w, (float*)nullptr, fmax_buf, (float*)nullptr, (float*)nullptr, (int*)nullptr);
+                           pl.G, mscale, h, w, (float*)nullptr, fmax_buf, (float*)nullptr, (float*)nullptr, (int*)nullptr,
+                           CorrPackArgs{nullptr, nullptr, nullptr, nullptr});
         DVC_CHECK_LAUNCH("dvc_corr_fwd(merge1)");
         launch(true);
     } else {
         launch(false);
     }
     DVC_CHECK_LAUNCH("dvc_corr_fwd");
+    // every output NULL: the merge is left to the consumer (dvc_corr_merge_pack) — the partial states stay in `workspace`
+    if (!y_small && !sim_small && !y_up && !sim_up && !argmax) return 0;
     hipLaunchKernelGGL(corr_merge_kernel, mgrid, dim3(256), 0, s, a.part, a.nslot, P, pl.nqb, pl.ntiles, pl.U, pl.G,
-                       mscale, h, w, y_small, sim_small, y_up, sim_up, argmax);
+                       mscale, h, w, y_small, sim_small, y_up, sim_up, argmax, CorrPackArgs{nullptr, nullptr, nullptr, nullptr});
     DVC_CHECK_LAUNCH("dvc_corr_fwd(merge)");
+    return 0;
+}
+
+extern "C" int dvc_corr_merge_pack(const void* workspace, size_t workspace_bytes, float temperature, int32_t h, int32_t w,
+                                   const float* IA_l, const float* last_l, const float* last_ab, float* out7, float* y_up,
+                                   float* sim_up, dvcStream stream) {
+    DVC_REQUIRE(workspace && IA_l && last_l && last_ab && out7, "dvc_corr_merge_pack: null argument");
+    DVC_REQUIRE(h > 0 && w > 0 && temperature > 0.f && std::isfinite(temperature), "dvc_corr_merge_pack: bad shape / temperature");
+    const int P = h * w;
+    DVC_REQUIRE(workspace_bytes >= dvc_corr_workspace_bytes(1, P), "dvc_corr_merge_pack: workspace too small");
+    DVC_REQUIRE(((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(IA_l) | reinterpret_cast<uintptr_t>(last_l) |
+                  reinterpret_cast<uintptr_t>(last_ab) | reinterpret_cast<uintptr_t>(out7) | reinterpret_cast<uintptr_t>(y_up) |
+                  reinterpret_cast<uintptr_t>(sim_up)) & 15) == 0,
+                "dvc_corr_merge_pack: every plane must be 16-byte aligned");
+    const CorrPlan pl = corr_plan(1, P);
+    const int mode = temperature >= 1e-3f ? 1 : (120.f * temperature >= 1e-6f ? 2 : 0);       // as dvc_corr_fwd
+    const float mscale = mode == 2 ? (1.0f / temperature) * 1.44269504088896f : 0.f;
+    hipLaunchKernelGGL(corr_merge_kernel, dim3(cdiv(P, CORR_MQ), 1), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(workspace), pl.nslot, P, pl.nqb, pl.ntiles, pl.U, pl.G, mscale, h, w,
+                       (float*)nullptr, (float*)nullptr, y_up, sim_up, (int*)nullptr, CorrPackArgs{out7, IA_l, last_l, last_ab});
+    DVC_CHECK_LAUNCH("dvc_corr_merge_pack");
     return 0;
 }

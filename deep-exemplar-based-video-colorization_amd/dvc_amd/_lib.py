@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DVC_DEBUG_LIB=1 (tools/ only) loads the -DDVC_DEBUG build, the only one that carries the dvc_debug_* hooks
 DEBUG_BUILD = os.environ.get("DVC_DEBUG_LIB", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "libdvc_hip_debug.so" if DEBUG_BUILD else "libdvc_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -86,6 +86,7 @@ SIGNATURES = {
     "dvc_corr_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "dvc_corr_fwd": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_float, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,
                                     _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_size_t, _VP]),
+    "dvc_corr_merge_pack": (ctypes.c_int, [_VP, ctypes.c_size_t, ctypes.c_float, c_i32, c_i32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "dvc_corr_prepare_bf16": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP, _VP]),
     "dvc_corr_bf16_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "dvc_corr_fwd_bf16": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,

@@ -10,8 +10,10 @@ VGG_OUT = ["r12", "r22", "r32", "r42", "r52"]
 
 
 def warp_color(IA_l, IB_lab, features_B, vggnet, nonlocal_net, colornet, feature_noise=0, temperature=0.01,
-               exemplar_cache=None):
-    """models/FrameColor.py:5-38.  `colornet` and `feature_noise` are unused there as well."""
+               exemplar_cache=None, defer_merge=False):
+    """models/FrameColor.py:5-38.  `colornet` and `feature_noise` are unused there as well.
+    defer_merge (not upstream): the correlation's merge is left to ops.pack_color_input — `nonlocal_BA_lab` is then an
+    ops.CorrPartials and `similarity_map` None (the fp32 correlation only; the bf16 candidate filter returns tensors)."""
     IA_rgb_from_gray = gray2rgb_batch(IA_l)
     A_relu1_1, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1 = vggnet(IA_rgb_from_gray, VGG_OUT, preprocess=True)
     if exemplar_cache is None:
@@ -21,11 +23,13 @@ def warp_color(IA_l, IB_lab, features_B, vggnet, nonlocal_net, colornet, feature
     nA = ops.channel_l2norm_multi(features_A[1:])            # feature_normalize x4 (FrameColor.py:16-19), one launch
     if exemplar_cache is None:
         nB = ops.channel_l2norm_multi((B_relu2_1, B_relu3_1, B_relu4_1, B_relu5_1))
-        nonlocal_BA_lab, similarity_map = nonlocal_net(IB_lab, *nA, *nB, temperature=temperature)
+        kw = dict(defer_merge=True) if defer_merge else {}
+        nonlocal_BA_lab, similarity_map = nonlocal_net(IB_lab, *nA, *nB, temperature=temperature, **kw)
     else:
         # exemplar side cached: the B feature arguments are not read (pass the A ones as placeholders)
+        kw = dict(defer_merge=True) if defer_merge else {}
         nonlocal_BA_lab, similarity_map = nonlocal_net(IB_lab, *nA, *nA, temperature=temperature,
-                                                       exemplar_cache=exemplar_cache)
+                                                       exemplar_cache=exemplar_cache, **kw)
     return nonlocal_BA_lab, similarity_map, features_A
 
 
@@ -43,12 +47,15 @@ def frame_colorization(IA_lab, IB_lab, IA_last_lab, features_B, vggnet, nonlocal
         IA_lab_in = torch.cat((IA_l, IA_lab[:, 1:3]), dim=1).contiguous()
     else:
         IA_lab_in = IA_lab
+    # (the correlation's merge is folded into the launch that builds ColorVidNet's input, which also writes the warped Lab this
+    # function returns: ops.pack_color_input(want_warped=True); modules that are not this package's WarpNet get the plain call)
+    fold = ops.fold_merge() and hasattr(nonlocal_net, "exemplar_side")
     nonlocal_BA_lab, similarity_map, features_A_gray = warp_color(
         IA_l, IB_lab, features_B, vggnet, nonlocal_net, colornet, feature_noise, temperature=temperature,
-        exemplar_cache=exemplar_cache)
+        exemplar_cache=exemplar_cache, defer_merge=fold)
     # cat((IA_l, nonlocal_BA_ab, similarity_map, IA_last_lab), dim=1)  (FrameColor.py:63-64)
-    color_input = ops.pack_color_input(IA_lab_in, nonlocal_BA_lab, similarity_map,
-                                       IA_last_lab.detach().contiguous().float())
+    color_input, nonlocal_BA_lab = ops.pack_color_input(IA_lab_in, nonlocal_BA_lab, similarity_map,
+                                                        IA_last_lab.detach().contiguous().float(), want_warped=True)
     IA_ab_predict = colornet(color_input)
     return IA_ab_predict, nonlocal_BA_lab, features_A_gray
 
@@ -63,8 +70,8 @@ class _FrontSlot:
 
         def front():
             warped, sim, _ = warp_color(self.IA_in[:, 0:1], cc.IB_lab, None, cc.vgg, cc.warp, cc.col, 0,
-                                        temperature=cc.temperature, exemplar_cache=cc.ex_cache)
-            return warped, sim
+                                        temperature=cc.temperature, exemplar_cache=cc.ex_cache, defer_merge=ops.fold_merge())
+            return warped, sim      # (fp32 correlation with the merge folded into the consumer: (ops.CorrPartials, None))
 
         self.seq = CapturedSequence(front, stream)
         self.warped, self.sim = self.seq.out
@@ -271,8 +278,9 @@ class ClipColorizer:
         if self.n_refs > 1:     # one frame against the R references: IA_last_lab [R,3,H,W] -> (ab [R,2,H,W], warped [R,3,H,W])
             IA_lab = IA_lab.detach().contiguous().float()
             warped, sim, _ = warp_color(IA_lab[:, 0:1], self.IB_lab, None, self.vgg, self.warp, self.col, 0,
-                                        temperature=self.temperature, exemplar_cache=self.ex_cache)
-            cin = ops.pack_color_input(self._rep(IA_lab), warped, sim, IA_last_lab.detach().contiguous().float())
+                                        temperature=self.temperature, exemplar_cache=self.ex_cache, defer_merge=ops.fold_merge())
+            cin, warped = ops.pack_color_input(self._rep(IA_lab), warped, sim, IA_last_lab.detach().contiguous().float(),
+                                               want_warped=True)
             return self._chain(cin), warped
         if self.graph if graph is None else graph:
             return self._frame_graph(IA_lab.detach().contiguous().float(),
@@ -290,9 +298,9 @@ class ClipColorizer:
         chain = self._captured("color", IA_lab.shape, IA_lab.device, 0, self._capture_stream())
         front.IA_in.copy_(IA_lab)
         front.seq.replay()
-        ops.pack_color_input(IA_lab, front.warped, front.sim, out=chain.cin, **prev)
+        _, warped = ops.pack_color_input(IA_lab, front.warped, front.sim, out=chain.cin, want_warped=True, **prev)
         chain.seq.replay()
-        return chain.ab.clone(), front.warped.clone()
+        return chain.ab.clone(), (warped.clone() if warped is front.warped else warped)
 
     def clip(self, frames_lab, frame_propagate=False, last=None, lookahead=2, on_frame=None, front_batch=1, graph=None):
         """Recurrence of test.py:68-96; returns the list of ab predictions.
@@ -345,7 +353,8 @@ class ClipColorizer:
                 else:
                     IA_l = IA_lab[:, 0:1]
                     warped, sim, _ = warp_color(IA_l, self.IB_lab, self.features_B, self.vgg, self.warp, self.col, 0,
-                                                temperature=self.temperature, exemplar_cache=self.ex_cache)
+                                                temperature=self.temperature, exemplar_cache=self.ex_cache,
+                                                defer_merge=ops.fold_merge())
                     ab = self._chain(ops.pack_color_input(self._rep(IA_lab), warped, sim, **prev))
                 prev = dict(last_l=self._rep(IA_lab), last_ab=ab)
                 outs.append(ab)
@@ -377,7 +386,7 @@ class ClipColorizer:
                 IA_lab = fr[0] if len(fr) == 1 else torch.cat(fr, dim=0)
                 warped, sim, _ = warp_color(IA_lab[:, 0:1], self.IB_lab, self.features_B, self.vgg, self.warp,
                                             self.col, 0, temperature=self.temperature,
-                                            exemplar_cache=self.ex_cache)
+                                            exemplar_cache=self.ex_cache, defer_merge=ops.fold_merge() and nb == 1)
                 ev = torch.cuda.Event()
                 ev.record(s)
             fronts[bi] = (IA_lab, warped, sim, ev)
@@ -388,10 +397,13 @@ class ClipColorizer:
             IA_b, warped_b, sim_b, ev = fronts.pop(bi)
             cur.wait_event(ev)
             for x in (IA_b, warped_b, sim_b):
-                x.record_stream(cur)    # allocated on a side stream, consumed here
+                if x is not None:
+                    x.record_stream(cur)    # allocated on a side stream, consumed here
             for j, t in enumerate(members):
                 if multi:       # (one frame per set of front-end launches; its warped colours / similarity carry R images)
                     IA_lab, warped, sim = self._rep(IA_b), warped_b, sim_b
+                elif nb == 1:
+                    IA_lab, warped, sim = IA_b, warped_b, sim_b
                 else:
                     IA_lab, warped, sim = IA_b[j:j + 1], warped_b[j:j + 1], sim_b[j:j + 1]
                 with torch.cuda.stream(cur):
@@ -436,9 +448,11 @@ class ClipColorizer:
                 slot.IA_in.copy_(frames_lab[t])
                 if eager_front:
                     w_, s_, _ = warp_color(slot.IA_in[:, 0:1], self.IB_lab, None, self.vgg, self.warp, self.col, 0,
-                                           temperature=self.temperature, exemplar_cache=self.ex_cache)
+                                           temperature=self.temperature, exemplar_cache=self.ex_cache,
+                                           defer_merge=isinstance(slot.warped, ops.CorrPartials))
                     slot.warped.copy_(w_)
-                    slot.sim.copy_(s_)
+                    if s_ is not None:
+                        slot.sim.copy_(s_)
                 else:
                     slot.seq.replay()
                 ev = torch.cuda.Event()

@@ -25,7 +25,8 @@ from . import nets, ops
 
 def _epoch():
     """Everything that decides WHICH launches a sequence consists of."""
-    return (nets.pack_epoch(), ops.conv_algo(), ops.fuse_reduce(), ops.pool_fusion(), ops.dual_conv_enabled(), ops.autotune_enabled())
+    return (nets.pack_epoch(), ops.conv_algo(), ops.fuse_reduce(), ops.pool_fusion(), ops.dual_conv_enabled(), ops.autotune_enabled(),
+            ops.fold_merge())
 
 
 class CapturedSequence:

@@ -316,7 +316,10 @@ class WarpNet(nn.Module):
 
     def forward(self, B_lab_map, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1, B_relu2_1, B_relu3_1,
                 B_relu4_1, B_relu5_1, temperature=0.001 * 5, detach_flag=False, WTA_scale_weight=1,
-                feature_noise=0, exemplar_cache=None, return_taps=False):
+                feature_noise=0, exemplar_cache=None, return_taps=False, defer_merge=False):
+        """models/NonlocalNet.py:427-502 -> (y, similarity_map).  Not upstream: `exemplar_cache` (the exemplar side computed once
+        per clip), `return_taps`, and `defer_merge` — the fp32 correlation then leaves the merge of its partial softmax states
+        to the consumer and the call returns (ops.CorrPartials, None) for ops.pack_color_input (dvc_amd/frame.py)."""
         ins = [B_lab_map, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1, B_relu2_1, B_relu3_1, B_relu4_1,
                B_relu5_1]
         for t in ins:
@@ -343,7 +346,9 @@ class WarpNet(nn.Module):
         else:
             res = ops.corr_fwd(theta, phi, blab.view(blab.shape[0], 3, -1), float(temperature), fh, fw,
                                wta_scale=float(WTA_scale_weight), want_small=return_taps,
-                               want_argmax=return_taps)
+                               want_argmax=return_taps, defer_merge=defer_merge and not return_taps)
+            if isinstance(res, ops.CorrPartials):
+                return res, None
         if return_taps:
             return res["y_up"], res["sim_up"], dict(theta=theta, phi=phi, y_small=res["y_small"],
                                                     sim_small=res["sim_small"], argmax=res["argmax"],

@@ -673,6 +673,39 @@ def lab2rgb(lab, l_offset=0.0):
     return y
 
 
+# the merge of the correlation's partial softmax states folded into its consumer (pack_color_input): DVC_FOLD_MERGE=0 / set_fold_merge
+_fold_merge = _os.environ.get("DVC_FOLD_MERGE", "1") == "1"
+
+
+def fold_merge():
+    return _fold_merge
+
+
+def set_fold_merge(flag=True):
+    global _fold_merge
+    _fold_merge = bool(flag)
+
+
+class CorrPartials:
+    """What corr_fwd(..., defer_merge=True) returns: the per-workgroup partial softmax states of B images (one private
+    buffer per image), still to be merged.  The one consumer is pack_color_input, whose launch then merges them and writes the
+    warped colours / similarity map straight into ColorVidNet's 7-channel input (dvc_corr_merge_pack) — no warped-Lab /
+    similarity tensors, no merge launch, no separate pack launch."""
+
+    def __init__(self, bufs, h, w, temperature):
+        self.bufs, self.h, self.w, self.temperature = list(bufs), h, w, float(temperature)
+        self.shape = (len(self.bufs), 3, 4 * h, 4 * w)      # of the warped Lab it stands for
+
+    def record_stream(self, stream):
+        for b in self.bufs:
+            b.record_stream(stream)
+
+    def copy_(self, other):
+        for a, b in zip(self.bufs, other.bufs):
+            a.copy_(b)
+        return self
+
+
 def _plane(t, ch, name):
     """(pointer, batch stride in elements) of channels ch.. of an [N,C,H,W] fp32 device tensor whose planes are dense
     (a contiguous tensor, or a channel slice of one)."""
@@ -688,12 +721,17 @@ def _plane(t, ch, name):
     return ctypes.c_void_p(t.data_ptr() + 4 * ch * H * W), ((t.stride(0) or -1) if N > 1 else C * H * W)
 
 
-def pack_color_input(IA_lab, warped_lab, sim, IA_last_lab=None, *, last_l=None, last_ab=None, out=None):
+def pack_color_input(IA_lab, warped_lab, sim, IA_last_lab=None, *, last_l=None, last_ab=None, out=None, want_warped=False):
     """cat((IA_l, warped ab, similarity, IA_last_lab), 1)  (FrameColor.py:63-64).  IA_lab: the current frame (channel 0 is
     read; a Lab tensor or its [:, 0:1] slice).  The previous frame is either `IA_last_lab` [N,3,H,W] or its two parts
     `last_l` (a tensor whose channel 0 is the previous luminance, e.g. the previous Lab frame) and `last_ab` [N,2,H,W] — the
-    clip loop passes the parts and never builds test.py:96's cat.  `out`: an existing [N,7,H,W] tensor (graph replay)."""
+    clip loop passes the parts and never builds test.py:96's cat.  `out`: an existing [N,7,H,W] tensor (graph replay).
+    `warped_lab` may be the CorrPartials of a deferred corr_fwd (`sim` is then None): this launch merges them (same arithmetic
+    as the merge inside corr_fwd, bit-identical values); want_warped=True additionally materialises the warped Lab
+    [N,3,H,W] (what FrameColor.py:41-67 returns) and the call returns (y, warped_lab)."""
     lib = _lib.load()
+    if isinstance(warped_lab, CorrPartials):
+        return _merge_pack(lib, IA_lab, warped_lab, IA_last_lab, last_l, last_ab, out, want_warped)
     for t, nm in ((warped_lab, "warped_lab"), (sim, "sim")):
         _need(t, nm)
     N, _, H, W = IA_lab.shape
@@ -713,7 +751,40 @@ def pack_color_input(IA_lab, warped_lab, sim, IA_last_lab=None, *, last_l=None, 
     y = torch.empty((N, 7, H, W), device=IA_lab.device, dtype=torch.float32) if out is None else out
     _lib.check(lib.dvc_pack_color_input(ia, ia_bs, _p(warped_lab), _p(sim), ll, ll_bs, la, la_bs, N, H * W, _p(y),
                                         _stream()), "dvc_pack_color_input")
-    return y
+    return (y, warped_lab) if want_warped else y
+
+
+def _merge_pack(lib, IA_lab, part, IA_last_lab, last_l, last_ab, out, want_warped):
+    """pack_color_input for the CorrPartials of a deferred corr_fwd: one dvc_corr_merge_pack launch per image."""
+    N, _, H, W = IA_lab.shape
+    if N != len(part.bufs) or (H, W) != (4 * part.h, 4 * part.w):
+        raise RuntimeError(f"dvc_amd: pack_color_input: frame {tuple(IA_lab.shape)} does not fit the correlation's {len(part.bufs)} x "
+                           f"{part.h} x {part.w} partial states")
+    HW = H * W
+    ia, ia_bs = _plane(IA_lab, 0, "IA_lab")
+    if IA_last_lab is not None:
+        ll, ll_bs = _plane(IA_last_lab, 0, "IA_last_lab")
+        la, la_bs = _plane(IA_last_lab, 1, "IA_last_lab")
+    else:
+        ll, ll_bs = _plane(last_l, 0, "last_l")
+        la, la_bs = _plane(last_ab, 0, "last_ab")
+        assert last_ab.shape[1] == 2
+    if out is not None:
+        _need(out, "out")
+        if tuple(out.shape) != (N, 7, H, W) or out.device != IA_lab.device:
+            raise RuntimeError(f"dvc_amd: pack_color_input: `out` must be a contiguous float32 [{N}, 7, {H}, {W}] tensor on {IA_lab.device}")
+    y = torch.empty((N, 7, H, W), device=IA_lab.device, dtype=torch.float32) if out is None else out
+    warped = torch.empty((N, 3, H, W), device=IA_lab.device, dtype=torch.float32) if want_warped else None
+    step = lambda bs: 0 if bs < 0 else 4 * bs           # noqa: E731  (bytes between images; -1 = the same plane for all)
+    st = _stream()
+    for n in range(N):
+        _lib.check(lib.dvc_corr_merge_pack(ctypes.c_void_p(part.bufs[n].data_ptr()), part.bufs[n].numel(), part.temperature,
+                                           part.h, part.w, ctypes.c_void_p(ia.value + n * step(ia_bs)),
+                                           ctypes.c_void_p(ll.value + n * step(ll_bs)), ctypes.c_void_p(la.value + n * step(la_bs)),
+                                           ctypes.c_void_p(y.data_ptr() + n * 7 * HW * 4),
+                                           None if warped is None else ctypes.c_void_p(warped.data_ptr() + n * 3 * HW * 4),
+                                           None, st), "dvc_corr_merge_pack")
+    return (y, warped) if want_warped else y
 
 
 def corr_prepare(t_raw, eps=EPS64):
@@ -764,18 +835,22 @@ def _workspace(device, nbytes, tag="corr"):
 
 
 def corr_fwd(theta, phi, blab, temperature, h, w, wta_scale=1.0, want_small=False, want_argmax=False,
-             want_up=True):
+             want_up=True, defer_merge=False):
     """Fused affinity + softmax + colour gather.  theta/phi: [B,256,P]; blab: [B,3,P] (P = h*w).
     Returns dict with y_up [B,3,4h,4w], sim_up [B,1,4h,4w] and optionally y_small / sim_small / argmax.
     Batch forms: paired (theta, phi, blab all [B]); one exemplar for B frames (phi / blab [1]: the clip driver's batched
     front ends); ONE FRAME AGAINST R EXEMPLARS (theta [1], phi / blab [R]: the references of a clip colourised in one pass,
     test.py:169-181) — outputs then have R images.  The library runs one image per set of launches in every form, so an
-    image's result never depends on the form it came in."""
+    image's result never depends on the form it came in.
+    defer_merge=True (wta_scale == 1, no small / arg-max outputs): the merge of the partial softmax states is left to the
+    consumer — returns the CorrPartials for pack_color_input instead of the dict."""
     lib = _lib.load()
     for t, nm in ((theta, "theta"), (phi, "phi"), (blab, "blab")):
         _need(t, nm)
     Bt, C, P = theta.shape
     R = phi.shape[0]
+    if defer_merge and (wta_scale != 1.0 or want_small or want_argmax):
+        defer_merge = False
     shared = Bt > 1 and R == 1 and blab.shape[0] == 1        # one exemplar for a batch of frames (clip driver)
     refs = Bt == 1 and R > 1 and blab.shape[0] == R          # one frame against R exemplars
     B = max(Bt, R)
@@ -784,6 +859,16 @@ def corr_fwd(theta, phi, blab, temperature, h, w, wta_scale=1.0, want_small=Fals
     if not (temperature > 0):
         raise ValueError("temperature must be > 0")
     dev = theta.device
+    if defer_merge:
+        # one private partial-state buffer per image (2 MB at 54x96): the consumer may run on another stream, later
+        nb1 = lib.dvc_corr_workspace_bytes(1, P)
+        bufs = [torch.empty(nb1, device=dev, dtype=torch.uint8) for _ in range(B)]
+        st = _stream()
+        for b in range(B):
+            th, ph, bl = theta[b if Bt > 1 else 0], phi[b if R > 1 else 0], blab[b if blab.shape[0] > 1 else 0]
+            _lib.check(lib.dvc_corr_fwd(_p(th), _p(ph), _p(bl), float(temperature), 1.0, 1, C, h, w, None, None, None, None, None,
+                                        ctypes.c_void_p(bufs[b].data_ptr()), bufs[b].numel(), st), "dvc_corr_fwd")
+        return CorrPartials(bufs, h, w, temperature)
     out = {}
     y_up = sim_up = y_small = sim_small = amax = None
     if want_up:

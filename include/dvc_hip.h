@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 12
+#define DVC_ABI_VERSION 13
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -306,11 +306,24 @@ size_t dvc_corr_workspace_bytes(int32_t B, int32_t P);
  * otherwise f' = (f == rowmax f) ? f : f * wta_scale (WTA_scale.forward, NonlocalNet.py:295-309).
  * Outputs (any may be NULL): y_small [B][3][h][w], sim_small [B][1][h][w] with h*w == P,
  * y_up [B][3][4h][4w], sim_up [B][1][4h][4w], argmax [B][P] (index of the largest affinity per row,
- * lowest index on exact ties). */
+ * lowest index on exact ties).
+ * With EVERY output NULL (B == 1, wta_scale == 1) the merge of the per-workgroup partial softmax states is left to the
+ * consumer: they stay in `workspace` (dvc_corr_workspace_bytes(1, P) bytes, which the caller then must not reuse) for
+ * dvc_corr_merge_pack. */
 int dvc_corr_fwd(const float* theta, const float* phi, const float* blab, float temperature,
                  float wta_scale, int32_t B, int32_t C, int32_t h, int32_t w, float* y_small,
                  float* sim_small, float* y_up, float* sim_up, int32_t* argmax, void* workspace,
                  size_t workspace_bytes, dvcStream stream);
+
+/* The merge of a deferred dvc_corr_fwd (same temperature, h, w; `workspace` as that call left it) fused with the consumer of
+ * its results, cat((IA_l, nonlocal_BA_lab[:,1:3], similarity_map, IA_last_lab), 1) of models/FrameColor.py:63-64 (see
+ * dvc_pack_color_input) for ONE image: out7 [7][16 P]; IA_l, last_l: [16 P] planes; last_ab: [2][16 P].  The warped colours and
+ * the similarity map go straight into channels 1..3 (x4 nearest, NonlocalNet.py:499-500) and are additionally written to
+ * y_up [3][16 P] / sim_up [16 P] when those are not NULL (FrameColor.py:41-67 returns nonlocal_BA_lab).  Same arithmetic, same
+ * order as the merge inside dvc_corr_fwd: bit-identical values.  Every pointer 16-byte aligned. */
+int dvc_corr_merge_pack(const void* workspace, size_t workspace_bytes, float temperature, int32_t h, int32_t w,
+                        const float* IA_l, const float* last_l, const float* last_ab, float* out7,
+                        float* y_up /* or NULL */, float* sim_up /* or NULL */, dvcStream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 mixed-precision correlation (BASELINE.json configs[4]).  Same reference lines as dvc_corr_fwd

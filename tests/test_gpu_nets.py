@@ -755,6 +755,44 @@ def test_graph_replay_notices_reloaded_weights_without_an_eager_call():
         assert not torch.equal(got, ab0)
 
 
+def test_folded_merge_is_bit_identical_in_the_drivers(nets):
+    """ops.set_fold_merge: with the correlation's merge folded into pack_color_input (default) and with the separate merge +
+    pack launches, frame_colorization (incl. the warped Lab it returns), the sequential and the pipelined clip and the
+    graph-replayed per-frame call give the same bits; one kernel launch less per frame on the recurrence's critical path and
+    one less in the front end."""
+    from dvc_amd import ops, synth
+    from dvc_amd.frame import VGG_OUT, ClipColorizer, frame_colorization
+    vgg, warp, col = nets
+    H, W = 48, 80
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).cuda()
+    frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W).cuda() for i in range(4)]
+    res = {}
+    old = ops.fold_merge()
+    try:
+        for fold in (True, False):
+            ops.set_fold_merge(fold)
+            fB = vgg(ops.lab2rgb(IB, l_offset=50.0), VGG_OUT)
+            ab, nl, _ = frame_colorization(frames[0], IB, torch.zeros_like(frames[0]), fB, vgg, warp, col, joint_training=False,
+                                           temperature=1e-10)
+            ab_s, nl_s, _ = frame_colorization(frames[1], IB, frames[0], fB, vgg, warp, col, joint_training=False, temperature=0.01)
+            cc = ClipColorizer(vgg, warp, col, temperature=1e-10)
+            cc.set_exemplar(IB)
+            seq = cc.clip(frames, lookahead=0)
+            pipe = cc.clip(frames, lookahead=2)
+            cg = ClipColorizer(vgg, warp, col, temperature=1e-10, graph=True)
+            cg.set_exemplar(IB)
+            gab, gnl = cg.frame(frames[0], torch.zeros_like(frames[0]))
+            gclip = cg.clip(frames, lookahead=2)
+            torch.cuda.synchronize()
+            res[fold] = [ab, nl, ab_s, nl_s] + seq + pipe + [gab, gnl] + gclip
+    finally:
+        ops.set_fold_merge(old)
+    assert len(res[True]) == len(res[False])
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        assert torch.equal(a, b), i
+    assert torch.equal(res[True][0], res[True][4]) and torch.equal(res[True][0], res[True][12])      # frame 0: all drivers agree
+
+
 def test_luminance_noise_path(nets):
     """frame_colorization(luminance_noise=s) (models/FrameColor.py:55-57) adds s * randn to the L channel that feeds BOTH
     the VGG front end and ColorVidNet's first input channel: equal, bit for bit, to a call with the same noise already

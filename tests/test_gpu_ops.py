@@ -910,6 +910,45 @@ def test_corr_fwd_wta(ops, h, w, B, T, scale):
     assert torch.equal(plain["y_small"], one["y_small"])
 
 
+@pytest.mark.parametrize("T", [1e-10, 1e-5, 0.01])
+@pytest.mark.parametrize("h,w,B", [(54, 96, 1), (9, 9, 2), (13, 24, 3), (7, 11, 1)])
+def test_corr_merge_folded_into_pack_color_input(ops, h, w, B, T):
+    """r04: the merge of the correlation's partial softmax states folded into its consumer.  corr_fwd(defer_merge=True) leaves
+    the per-workgroup states in a private buffer; pack_color_input (dvc_corr_merge_pack) merges them with the arithmetic and
+    order of the merge inside dvc_corr_fwd and writes warped ab / similarity straight into ColorVidNet's 7-channel input,
+    copying the four pure-data planes alongside: the 7-channel tensor and the optional warped Lab must equal the two-launch
+    form (corr_fwd -> pack_color_input on tensors) BIT FOR BIT, in every temperature regime, for odd sizes, batches, the
+    shared-theta form (one frame, R exemplars) and the previous frame given whole or as its two parts."""
+    g = torch.Generator().manual_seed(h * 31 + w + B)
+    P, H, W = h * w, 4 * h, 4 * w
+    th = ops.corr_prepare(torch.randn(B, 256, P, generator=g).cuda())
+    ph = ops.corr_prepare(torch.randn(B, 256, P, generator=g).cuda())
+    bl = (torch.randn(B, 3, P, generator=g) * 30).cuda()
+    IA = (torch.randn(B, 3, H, W, generator=g) * 20).cuda()
+    last = (torch.randn(B, 3, H, W, generator=g) * 20).cuda()
+    prev_l, prev_ab = (torch.randn(B, 3, H, W, generator=g) * 20).cuda(), (torch.randn(B, 2, H, W, generator=g) * 20).cuda()
+    ref = ops.corr_fwd(th, ph, bl, T, h, w)
+    part = ops.corr_fwd(th, ph, bl, T, h, w, defer_merge=True)
+    assert isinstance(part, ops.CorrPartials) and part.shape == (B, 3, H, W)
+    want = ops.pack_color_input(IA, ref["y_up"], ref["sim_up"], last)
+    got, warped = ops.pack_color_input(IA, part, None, last, want_warped=True)
+    assert torch.equal(got, want) and torch.equal(warped, ref["y_up"])
+    want2 = ops.pack_color_input(IA, ref["y_up"], ref["sim_up"], last_l=prev_l, last_ab=prev_ab)
+    out = torch.empty_like(want2)
+    got2 = ops.pack_color_input(IA, part, None, last_l=prev_l, last_ab=prev_ab, out=out)      # (the states can be merged again)
+    assert got2 is out and torch.equal(got2, want2)
+    if B > 1:       # one frame against B exemplars: theta shared, the frame's planes broadcast (batch stride -1)
+        ref1 = ops.corr_fwd(th[:1], ph, bl, T, h, w)
+        part1 = ops.corr_fwd(th[:1], ph, bl, T, h, w, defer_merge=True)
+        rep = IA[:1].expand(B, -1, -1, -1)
+        assert torch.equal(ops.pack_color_input(rep, part1, None, last), ops.pack_color_input(rep, ref1["y_up"], ref1["sim_up"], last))
+    # WTA / taps keep the materialised path
+    assert isinstance(ops.corr_fwd(th, ph, bl, T, h, w, wta_scale=0.5, defer_merge=True), dict)
+    assert isinstance(ops.corr_fwd(th, ph, bl, T, h, w, want_argmax=True, defer_merge=True), dict)
+    with pytest.raises(RuntimeError, match="does not fit"):
+        ops.pack_color_input(IA[:, :, :H - 4], part, None, last[:, :, :H - 4].contiguous())
+
+
 def test_util_shims_on_device(ops):
     """utils.util drop-ins executed on the device against the oracle's restatement of utils/util.py: vgg_preprocess
     (:347-352, standalone form), tensor_lab2rgb (:379-414), gray2rgb_batch (:97-101), feature_normalize (:155-158),
