@@ -123,6 +123,7 @@ class ClipColorizer:
         self._tail_stream = None
         self._graphs = {}            # (kind, shape, slot, ...) -> _FrontSlot / _ColorChain
         self._weights_fp = None      # (data_ptr, version) of every parameter when the weights were last packed
+        self._params = None          # (flat parameter list, first parameter of each network) behind that fingerprint
 
     def prepare(self):
         """Pack all weights of the three networks on the current stream (idempotent, cheap when warm)."""
@@ -136,7 +137,14 @@ class ClipColorizer:
         parameters: an in-place `load_state_dict` or a `.cuda()` is only noticed by `_PackCache.get`, i.e. by an eager
         forward or `prepare()` — a replayed graph calls neither.  The fingerprint costs ~140 attribute reads; `prepare()`
         runs only when it moved."""
-        fp = tuple((p.data_ptr(), p._version) for net in (self.vgg, self.warp, self.col) for p in net.parameters())
+        # (the Parameter objects survive load_state_dict / .cuda() — both write through `param.data` / in place — so the module
+        # trees are walked once; a replaced Parameter shows up as a changed data_ptr of a dead object only if somebody keeps
+        # assigning new nn.Parameter objects, which the identity check of the first parameters catches)
+        params = self._params
+        if params is None or any(a is not b for a, b in zip(params[1], (next(net.parameters()) for net in (self.vgg, self.warp, self.col)))):
+            plist = [p for net in (self.vgg, self.warp, self.col) for p in net.parameters()]
+            params = self._params = (plist, [next(net.parameters()) for net in (self.vgg, self.warp, self.col)])
+        fp = [(p.data_ptr(), p._version) for p in params[0]]
         if fp != self._weights_fp:
             self.prepare()
             self._weights_fp = fp
