@@ -74,14 +74,19 @@ extern "C" int dvc_cx_prepare(const float* x, const float* mean_in, int32_t cent
 // l_i = sum_j w_ij, r_i = max_j A_ij = w_{i j*} / l_i, E_i = sum_j A_ij d_ij.  One workgroup per row.
 __device__ __forceinline__ float cx_w(float s, float a, float h) { return expf((1.f - (1.f - s) / a) / h); }
 
-__global__ __launch_bounds__(256) void cx_rows_kernel(const float* __restrict__ S, int N, float h, float* __restrict__ a_out,
-                                                      int* __restrict__ jstar, float* __restrict__ l_out,
-                                                      float* __restrict__ r_out, float* __restrict__ e_out) {
+// (every kernel below takes a batch: blockIdx.y / .z = image; S_bs = elements between the images' S blocks, row_bs = between
+// their per-row arrays, which are [B][Nx] slices at the block's first row)
+__global__ __launch_bounds__(256) void cx_rows_kernel(const float* __restrict__ S, long S_bs, long row_bs, int N, float h,
+                                                      float* __restrict__ a_out, int* __restrict__ jstar,
+                                                      float* __restrict__ l_out, float* __restrict__ r_out,
+                                                      float* __restrict__ e_out) {
     __shared__ float redf[4];
     __shared__ int redi[4];
     __shared__ float red2[2][4];
     const int row = blockIdx.x;
-    const float* s = S + (long)row * N;
+    const long ro = (long)blockIdx.y * row_bs;
+    a_out += ro; jstar += ro; l_out += ro; r_out += ro; e_out += ro;
+    const float* s = S + (long)blockIdx.y * S_bs + (long)row * N;
     float m = -INFINITY;
     int mi = 0x7fffffff;
     for (int j = threadIdx.x; j < N; j += 256) {
@@ -123,21 +128,24 @@ __global__ __launch_bounds__(256) void cx_rows_kernel(const float* __restrict__ 
     }
 }
 
-extern "C" int dvc_cx_rows(const float* S, int32_t rows, int32_t N, float h, float* a, int32_t* jstar, float* l, float* r, float* e,
-                           dvcStream stream) {
-    DVC_REQUIRE(S && a && jstar && l && r && e && rows > 0 && N > 0 && h > 0.f, "dvc_cx_rows: bad argument");
-    hipLaunchKernelGGL(cx_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, S, N, h, a, jstar, l, r, e);
+extern "C" int dvc_cx_rows(const float* S, int32_t nb, int64_t S_bs, int64_t row_bs, int32_t rows, int32_t N, float h, float* a,
+                           int32_t* jstar, float* l, float* r, float* e, dvcStream stream) {
+    DVC_REQUIRE(S && a && jstar && l && r && e && nb > 0 && nb < 65536 && rows > 0 && N > 0 && h > 0.f, "dvc_cx_rows: bad argument");
+    hipLaunchKernelGGL(cx_rows_kernel, dim3(rows, nb), dim3(256), 0, (hipStream_t)stream, S, (long)S_bs, (long)row_bs, N, h, a, jstar,
+                       l, r, e);
     DVC_CHECK_LAUNCH("dvc_cx_rows");
     return 0;
 }
 
 // ---- ContextualLoss (max over ROWS for every column): running column maxima of A over the row blocks.
 // Thread = column; rows walked in order (coalesced along j), strict '>' keeps the lowest row index on ties.
-__global__ __launch_bounds__(256) void cx_colmax_kernel(const float* __restrict__ S, const float* __restrict__ a,
-                                                        const float* __restrict__ l, int rows, int N, int i0, float h,
-                                                        float* __restrict__ cmax, int* __restrict__ cargi) {
+__global__ __launch_bounds__(256) void cx_colmax_kernel(const float* __restrict__ S, long S_bs, long row_bs,
+                                                        const float* __restrict__ a, const float* __restrict__ l, int rows, int N,
+                                                        int i0, float h, float* __restrict__ cmax, int* __restrict__ cargi) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
+    S += (long)blockIdx.y * S_bs; a += (long)blockIdx.y * row_bs; l += (long)blockIdx.y * row_bs;
+    cmax += (long)blockIdx.y * N; cargi += (long)blockIdx.y * N;
     float best = cmax[j];
     int bi = cargi[j];
     for (int i = 0; i < rows; ++i) {
@@ -148,11 +156,11 @@ __global__ __launch_bounds__(256) void cx_colmax_kernel(const float* __restrict_
     cargi[j] = bi;
 }
 
-extern "C" int dvc_cx_colmax(const float* S, const float* a, const float* l, int32_t rows, int32_t N, int32_t row0, float h,
-                             float* cmax, int32_t* cargi, dvcStream stream) {
-    DVC_REQUIRE(S && a && l && cmax && cargi && rows > 0 && N > 0 && h > 0.f, "dvc_cx_colmax: bad argument");
-    hipLaunchKernelGGL(cx_colmax_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, S, a, l, rows, N, row0, h, cmax,
-                       cargi);
+extern "C" int dvc_cx_colmax(const float* S, int32_t nb, int64_t S_bs, int64_t row_bs, const float* a, const float* l, int32_t rows,
+                             int32_t N, int32_t row0, float h, float* cmax, int32_t* cargi, dvcStream stream) {
+    DVC_REQUIRE(S && a && l && cmax && cargi && nb > 0 && nb < 65536 && rows > 0 && N > 0 && h > 0.f, "dvc_cx_colmax: bad argument");
+    hipLaunchKernelGGL(cx_colmax_kernel, dim3(cdiv(N, 256), nb), dim3(256), 0, (hipStream_t)stream, S, (long)S_bs, (long)row_bs, a, l,
+                       rows, N, row0, h, cmax, cargi);
     DVC_CHECK_LAUNCH("dvc_cx_colmax");
     return 0;
 }
@@ -162,6 +170,7 @@ __global__ __launch_bounds__(256) void cx_finish_kernel(const float* __restrict_
                                                         float* __restrict__ gscale) {
     __shared__ double red[4];
     double s = 0.0;
+    v += (long)blockIdx.x * n; loss += blockIdx.x; gscale += blockIdx.x;      // image blockIdx.x of a [B][n] array
     for (int i = threadIdx.x; i < n; i += 256) s += (double)v[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -174,21 +183,24 @@ __global__ __launch_bounds__(256) void cx_finish_kernel(const float* __restrict_
     }
 }
 
-extern "C" int dvc_cx_finish(const float* v, int32_t n, float* loss, float* gscale, dvcStream stream) {
-    DVC_REQUIRE(v && loss && gscale && n > 0, "dvc_cx_finish: bad argument");
-    hipLaunchKernelGGL(cx_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, v, n, loss, gscale);
+extern "C" int dvc_cx_finish(const float* v, int32_t nb, int32_t n, float* loss, float* gscale, dvcStream stream) {
+    DVC_REQUIRE(v && loss && gscale && nb > 0 && n > 0, "dvc_cx_finish: bad argument");
+    hipLaunchKernelGGL(cx_finish_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, v, n, loss, gscale);
     DVC_CHECK_LAUNCH("dvc_cx_finish");
     return 0;
 }
 
 // ---- backward, ContextualLoss only: per row i, T_i = sum_{k: argmax_i'(A_i'k) = i} A_ik and Q_i = the same sum weighted
 // by d_ik (the columns whose maximum sits in row i).  One workgroup per row, columns in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void cx_rows_tq_kernel(const float* __restrict__ S, const float* __restrict__ a,
-                                                         const float* __restrict__ l, const int* __restrict__ cargi, int N,
-                                                         int i0, float h, float* __restrict__ t_out, float* __restrict__ q_out) {
+__global__ __launch_bounds__(256) void cx_rows_tq_kernel(const float* __restrict__ S, long S_bs, long row_bs, long tq_bs,
+                                                         const float* __restrict__ a, const float* __restrict__ l,
+                                                         const int* __restrict__ cargi, int N, int i0, float h,
+                                                         float* __restrict__ t_out, float* __restrict__ q_out) {
     __shared__ float red[2][4];
     const int row = blockIdx.x;
-    const float* s = S + (long)row * N;
+    a += (long)blockIdx.y * row_bs; l += (long)blockIdx.y * row_bs; cargi += (long)blockIdx.y * N;
+    t_out += (long)blockIdx.y * tq_bs; q_out += (long)blockIdx.y * tq_bs;
+    const float* s = S + (long)blockIdx.y * S_bs + (long)row * N;
     const float ai = a[row], li = l[row];
     float t = 0.f, q = 0.f;
     for (int j = threadIdx.x; j < N; j += 256)
@@ -220,12 +232,22 @@ __global__ __launch_bounds__(256) void cx_ds_kernel(const float* __restrict__ S,
                                                     const int* __restrict__ cargi, const float* __restrict__ tt,
                                                     const float* __restrict__ qq, const float* __restrict__ gscale, float gout,
                                                     int mode, int rows, int N, int i0, int ldt, float h,
-                                                    float* __restrict__ dS, float* __restrict__ dST) {
+                                                    float* __restrict__ dS, float* __restrict__ dST, long S_bs, long row_bs,
+                                                    long tq_bs) {
     __shared__ float tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int j0 = blockIdx.x * 64, ib = blockIdx.y * 64;
     const int j = j0 + tx;
     const bool jok = j < N;
+    {   // image blockIdx.z
+        const long b = blockIdx.z;
+        S += b * S_bs; a += b * row_bs; l += b * row_bs; r += b * row_bs; e += b * row_bs; jstar += b * row_bs;
+        if (cargi) cargi += b * N;
+        if (tt) { tt += b * tq_bs; qq += b * tq_bs; }
+        gscale += b;
+        if (dS) dS += b * S_bs;
+        dST += b * (long)N * ldt;
+    }
     const float g = *gscale * gout;
     const int cj = (mode == 1 && jok) ? cargi[j] : -1;
 #pragma unroll 4
@@ -259,22 +281,25 @@ __global__ __launch_bounds__(256) void cx_ds_kernel(const float* __restrict__ S,
     }
 }
 
-extern "C" int dvc_cx_ds(const float* S, const float* a, const float* l, const float* r, const float* e, const int32_t* jstar,
-                         const int32_t* cargi, const float* t, const float* q, const float* gscale, float gout, int32_t mode,
-                         int32_t rows, int32_t N, int32_t row0, int32_t ld_t, float h, float* dS, float* dST, dvcStream stream) {
-    DVC_REQUIRE(S && a && l && r && e && jstar && gscale && dST && rows > 0 && N > 0 && ld_t >= rows && h > 0.f,
+extern "C" int dvc_cx_ds(const float* S, int32_t nb, int64_t S_bs, int64_t row_bs, int64_t tq_bs, const float* a, const float* l,
+                         const float* r, const float* e, const int32_t* jstar, const int32_t* cargi, const float* t, const float* q,
+                         const float* gscale, float gout, int32_t mode, int32_t rows, int32_t N, int32_t row0, int32_t ld_t, float h,
+                         float* dS, float* dST, dvcStream stream) {
+    DVC_REQUIRE(S && a && l && r && e && jstar && gscale && dST && nb > 0 && nb < 65536 && rows > 0 && N > 0 && ld_t >= rows && h > 0.f,
                 "dvc_cx_ds: bad argument");
     DVC_REQUIRE(mode == 0 || (mode == 1 && cargi && t && q), "dvc_cx_ds: mode 1 needs the column arg-max and the T / Q row sums");
-    hipLaunchKernelGGL(cx_ds_kernel, dim3(cdiv(N, 64), cdiv(ld_t, 64)), dim3(256), 0, (hipStream_t)stream, S, a, l, r, e, jstar,
-                       cargi, t, q, gscale, gout, mode, rows, N, row0, ld_t, h, dS, dST);
+    hipLaunchKernelGGL(cx_ds_kernel, dim3(cdiv(N, 64), cdiv(ld_t, 64), nb), dim3(256), 0, (hipStream_t)stream, S, a, l, r, e, jstar,
+                       cargi, t, q, gscale, gout, mode, rows, N, row0, ld_t, h, dS, dST, (long)S_bs, (long)row_bs, (long)tq_bs);
     DVC_CHECK_LAUNCH("dvc_cx_ds");
     return 0;
 }
 
-extern "C" int dvc_cx_rows_tq(const float* S, const float* a, const float* l, const int32_t* cargi, int32_t rows, int32_t N,
-                              int32_t row0, float h, float* t, float* q, dvcStream stream) {
-    DVC_REQUIRE(S && a && l && cargi && t && q && rows > 0 && N > 0 && h > 0.f, "dvc_cx_rows_tq: bad argument");
-    hipLaunchKernelGGL(cx_rows_tq_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, S, a, l, cargi, N, row0, h, t, q);
+extern "C" int dvc_cx_rows_tq(const float* S, int32_t nb, int64_t S_bs, int64_t row_bs, int64_t tq_bs, const float* a, const float* l,
+                              const int32_t* cargi, int32_t rows, int32_t N, int32_t row0, float h, float* t, float* q,
+                              dvcStream stream) {
+    DVC_REQUIRE(S && a && l && cargi && t && q && nb > 0 && nb < 65536 && rows > 0 && N > 0 && h > 0.f, "dvc_cx_rows_tq: bad argument");
+    hipLaunchKernelGGL(cx_rows_tq_kernel, dim3(rows, nb), dim3(256), 0, (hipStream_t)stream, S, (long)S_bs, (long)row_bs, (long)tq_bs, a,
+                       l, cargi, N, row0, h, t, q);
     DVC_CHECK_LAUNCH("dvc_cx_rows_tq");
     return 0;
 }

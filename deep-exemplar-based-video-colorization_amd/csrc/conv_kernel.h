@@ -55,6 +55,7 @@ struct ConvKArgs {
     int act, in_prelu;
     float act_slope;
     long x_bs, y_bs, res_bs;
+    long w_bs;             // filter batch stride (0: one filter set for the batch; != 0: image n uses w + n * w_bs, a batched GEMM)
     int IH_T, IW_T, IW_P;  // LDS input-patch geometry (authoritative only for GEN kernels)
     int cin_pad;           // Cin rounded up to a multiple of 4
     int split;             // split-K factor S (1 = off): blockIdx.z = n*S + s, raw partial sums go to `part`
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(RM * RN, TW, DIL, GEN,
     const int n = blockIdx.z / a.split, ksplit = blockIdx.z % a.split;
     const int HWi = a.H * a.W;  // tensors are < 2^31 elements
     const float* xn = a.x + (long)n * a.x_bs;
+    const float* wn_ = a.w + (long)n * a.w_bs;
     const bool affine = a.in_scale != nullptr;
     const float in_slope = a.in_prelu ? *a.in_slope_ptr : 0.f;
     const int vy0 = oy0 * stride - a.pad, vx0 = ox0 * stride - a.pad;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(RM * RN, TW, DIL, GEN,
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             bool ok = wofs[i] >= 0 && (!ragged || c0 + (tid + i * NT) / (KK * ROW4) < a.Cin);
-            wr[i] = *reinterpret_cast<const float4*>(a.w + (ok ? (unsigned)(wbase + wofs[i]) : 0u));
+            wr[i] = *reinterpret_cast<const float4*>(wn_ + (ok ? (unsigned)(wbase + wofs[i]) : 0u));
         }
     };
     // transform + write the prefetched chunk `ci` into LDS buffer `buf`
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(RM * RN, TW, DIL, GEN,
     const bool dbg_nox = kDvcDebug && (a.dbg == 1 || a.dbg == 2), dbg_now = kDvcDebug && (a.dbg == 1 || a.dbg == 3);
     auto issue_dma = [&](int ci, float* xs, float* ws) {
         const float* xc = xn + (long)ci * CK * HWi;
-        const float* wc = a.w + (long)ci * CK * KK * a.Cout;
+        const float* wc = wn_ + (long)ci * CK * KK * a.Cout;
 #pragma unroll
         for (int t = 0; t < EPT; ++t)
             if (gofs[t] >= 0 && !(dbg_nox && ci != c_begin))

@@ -200,10 +200,14 @@ static int conv2d_images(const DvcConvDesc* d, const float* x, const float* w_pa
     a.cin_pad = (d->Cin + 3) & ~3;
     a.dbg = g_conv_dbg;
     a.dbg_buf = g_conv_dbg_buf;
+    a.w_bs = d->w_batch_stride;
+    DVC_REQUIRE(d->w_batch_stride >= 0 && d->w_batch_stride % 4 == 0, "dvc_conv2d: w_batch_stride must be a multiple of 4 (got %ld)",
+                (long)d->w_batch_stride);
+    DVC_REQUIRE(d->w_batch_stride == 0 || d->cfg < 32, "dvc_conv2d: per-image filters run on the general engine only (cfg < 32)");
 
     // the two image-input layers (3 -> 64, 7 -> 32) have a kernel of their own (conv_image.hip); an explicit cfg / split_k keeps
     // the general engine reachable (tests, tools/conv_algo_sweep.py)
-    if (d->cfg < 0 && d->split_k == 0 && !(g_conv_dbg & 1024) && conv_image_launch(a, (hipStream_t)stream)) {
+    if (d->cfg < 0 && d->split_k == 0 && !d->w_batch_stride && !(g_conv_dbg & 1024) && conv_image_launch(a, (hipStream_t)stream)) {
         DVC_CHECK_LAUNCH("dvc_conv2d(image-input layer)");
         return 0;
     }
@@ -231,7 +235,7 @@ static int conv2d_images(const DvcConvDesc* d, const float* x, const float* w_pa
     // WarpNet and ColorVidNet and the two widest decoder layers): the stream-K decomposition with 64x64 tiles and two
     // workgroups per CU wins on every one of them (profiles/r02_conv_layer_sweep.json: 62-64 us against 67-75 us).
     int sk_per_cu = d->split_k;
-    if (cfg < 0 && d->split_k == 0 && workspace && !gen && !in_scale && !d->in_prelu && d->ksize == 3 && d->Cin >= 256 &&
+    if (cfg < 0 && d->split_k == 0 && !d->w_batch_stride && workspace && !gen && !in_scale && !d->in_prelu && d->ksize == 3 && d->Cin >= 256 &&
         d->Cin % 8 == 0 && d->Cout % 64 == 0 &&
         (size_t)2 * conv_num_cus() * 2 * 64 * 64 * sizeof(float) <= workspace_bytes &&
         (long)d->Cin * d->H * d->W * 4 < (1L << 31) && (long)d->Cin * 9 * d->Cout * 4 < (1L << 31)) {
@@ -393,7 +397,7 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     for (int n0 = 0; n0 < d->N;) {       // (one pass unless the split-K workspace is smaller than the batch needs)
         g.N = d->N - n0;
         int done = 0;
-        const int rc = conv2d_images(&g, x ? x + (long)n0 * x_bs : x, w_packed, bias,
+        const int rc = conv2d_images(&g, x ? x + (long)n0 * x_bs : x, w_packed ? w_packed + (long)n0 * d->w_batch_stride : w_packed, bias,
                                      in_scale ? in_scale + (long)n0 * d->Cin : nullptr,
                                      in_shift ? in_shift + (long)n0 * d->Cin : nullptr, in_slope_ptr, act_slope_ptr,
                                      residual ? residual + (long)n0 * r_bs : nullptr, y ? y + (long)n0 * y_bs : y, workspace,
@@ -602,7 +606,7 @@ static int wino_run(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x,
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long)d->Cout * OH * OW;
     a.res_bs = d->res_batch_stride ? d->res_batch_stride : (long)d->Cout * OH * OW;
     a.cin_pad = d->Cin; a.IH_T = a.IW_T = a.IW_P = 0;
-    a.dbg = g_conv_dbg; a.dbg_buf = nullptr;
+    a.dbg = g_conv_dbg; a.dbg_buf = nullptr; a.w_bs = 0;
     s.ss = d->dil;
     const int TY = cdiv(cdiv(OH, s.ss), 2), TX = cdiv(cdiv(OW, s.ss), 2);   // 2x2 tiles of one parity class
     int best_m = -1, best_tr = 1, best_S = 1;

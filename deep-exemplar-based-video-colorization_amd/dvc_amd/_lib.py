@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DVC_DEBUG_LIB=1 (tools/ only) loads the -DDVC_DEBUG build, the only one that carries the dvc_debug_* hooks
 DEBUG_BUILD = os.environ.get("DVC_DEBUG_LIB", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "libdvc_hip_debug.so" if DEBUG_BUILD else "libdvc_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -25,7 +25,7 @@ class DvcConvDesc(ctypes.Structure):
         ("pad", c_i32), ("pad_mode", c_i32), ("in_up", c_i32), ("in_sub", c_i32),
         ("act", c_i32), ("act_slope", ctypes.c_float), ("in_prelu", c_i32), ("cfg", c_i32), ("split_k", c_i32),
         ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("res_batch_stride", c_i64),
-        ("flags", c_i32),
+        ("flags", c_i32), ("w_batch_stride", c_i64),
     ]
 
 
@@ -54,12 +54,13 @@ SIGNATURES = {
     "dvc_instnorm_apply": (ctypes.c_int, [_VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i32, c_i32, c_i32,
                                           c_i32, c_i32, c_i64, c_i64, c_i64, _VP, _VP, _VP, _VP, c_i32, _VP, _VP]),
     "dvc_cx_prepare": (ctypes.c_int, [_VP, _VP, c_i32, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP, _VP]),
-    "dvc_cx_rows": (ctypes.c_int, [_VP, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "dvc_cx_colmax": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP]),
-    "dvc_cx_finish": (ctypes.c_int, [_VP, c_i32, _VP, _VP, _VP]),
-    "dvc_cx_rows_tq": (ctypes.c_int, [_VP, _VP, _VP, _VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP]),
-    "dvc_cx_ds": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,
-                                 c_i32, ctypes.c_float, _VP, _VP, _VP]),
+    "dvc_cx_rows": (ctypes.c_int, [_VP, c_i32, c_i64, c_i64, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "dvc_cx_colmax": (ctypes.c_int, [_VP, c_i32, c_i64, c_i64, _VP, _VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP]),
+    "dvc_cx_finish": (ctypes.c_int, [_VP, c_i32, c_i32, _VP, _VP, _VP]),
+    "dvc_cx_rows_tq": (ctypes.c_int, [_VP, c_i32, c_i64, c_i64, c_i64, _VP, _VP, _VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP,
+                                      _VP]),
+    "dvc_cx_ds": (ctypes.c_int, [_VP, c_i32, c_i64, c_i64, c_i64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_float, c_i32,
+                                 c_i32, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP]),
     "dvc_cx_normalize_bwd": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP]),
     "dvc_instnorm_apply_partials": (ctypes.c_int, [_VP, c_i32, _VP, c_i32, ctypes.c_float, _VP, _VP, _VP, _VP, ctypes.c_float,
                                                    c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, _VP, _VP, _VP,

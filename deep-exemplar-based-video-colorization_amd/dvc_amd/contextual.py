@@ -5,7 +5,7 @@ them: `contextual_forward_loss(predict_relu5_1, B_relu5_1.detach())` on VGG feat
 and of the exemplar (detached).  Same constructor / forward signatures, same per-sample return value [B].
 
     mu = mean_j Y;  Xn, Yn = (. - mu) / (||.||_C + eps)      dvc_cx_prepare
-    S  = Xn^T Yn  in blocks of R rows                         1x1-convolution engine (ops.conv2d)
+    S  = Xn^T Yn  in blocks of R rows, the whole batch at once  1x1-convolution engine with per-image filters (ops.conv2d)
     a_i, j*_i, l_i, r_i = max_j A_ij, E_i                     dvc_cx_rows          (A = softmax_j((1 - d / a_i) / h), d = 1 - S)
     column maxima of A over the rows (ContextualLoss only)    dvc_cx_colmax
     loss = -log mean(.)                                       dvc_cx_finish
@@ -54,21 +54,23 @@ class _ContextualCX(torch.autograd.Function):
         loss, gscale = torch.empty(B, **f32), torch.empty(B, **f32)
         R = min(ROW_BLOCK, (Nx + 63) // 64 * 64)
         hy, wy = (Y.shape[2], Y.shape[3]) if Y.dim() == 4 else (1, Ny)
-        S = torch.empty((1, R, hy, wy), **f32)
-        blk = torch.zeros((C, R), **f32)                 # K-major block of Xn columns (one buffer for every block)
-        for b in range(B):
-            y_img = Yn[b].view(1, C, hy, wy)
-            for i0 in range(0, Nx, R):
-                rows = min(R, Nx - i0)
-                _s_block(Xn[b], y_img, i0, rows, R, S, blk)
-                sl = slice(i0, i0 + rows)
-                _lib.check(lib.dvc_cx_rows(_p(S), rows, Ny, float(h), _p(a[b, sl]), _ip(jstar[b, sl]), _p(l[b, sl]), _p(r[b, sl]),
-                                           _p(e[b, sl]), st), "dvc_cx_rows")
-                if mode == 1:
-                    _lib.check(lib.dvc_cx_colmax(_p(S), _p(a[b, sl]), _p(l[b, sl]), rows, Ny, i0, float(h), _p(cmax[b]),
-                                                 _ip(cargi[b]), st), "dvc_cx_colmax")
-            v, n = (r[b], Nx) if mode == 0 else (cmax[b], Ny)
-            _lib.check(lib.dvc_cx_finish(_p(v), n, _p(loss[b:b + 1]), _p(gscale[b:b + 1]), st), "dvc_cx_finish")
+        # r04: the whole batch per launch — S[b] = Xn[b]^T Yn[b] is a 1x1 convolution with PER-IMAGE filters (a batched GEMM,
+        # DvcConvDesc.w_batch_stride) and the row / column kernels take the batch as a grid dimension
+        S = torch.empty((B, R, hy, wy), **f32)
+        blk = torch.zeros((B, C, 1, R), **f32)           # K-major blocks of Xn columns (one buffer for every block)
+        y_img = Yn.view(B, C, hy, wy)
+        S_bs = R * Ny
+        for i0 in range(0, Nx, R):
+            rows = min(R, Nx - i0)
+            _s_block(Xn, y_img, i0, rows, R, S, blk)
+            sl = slice(i0, i0 + rows)
+            _lib.check(lib.dvc_cx_rows(_p(S), B, S_bs, Nx, rows, Ny, float(h), _p(a[:, sl]), _ip(jstar[:, sl]), _p(l[:, sl]),
+                                       _p(r[:, sl]), _p(e[:, sl]), st), "dvc_cx_rows")
+            if mode == 1:
+                _lib.check(lib.dvc_cx_colmax(_p(S), B, S_bs, Nx, _p(a[:, sl]), _p(l[:, sl]), rows, Ny, i0, float(h), _p(cmax),
+                                             _ip(cargi), st), "dvc_cx_colmax")
+        v, n = (r, Nx) if mode == 0 else (cmax, Ny)
+        _lib.check(lib.dvc_cx_finish(_p(v), B, n, _p(loss), _p(gscale), st), "dvc_cx_finish")
         saved = [Xn, Yn, normX, a, l, r, e, jstar, gscale] + ([cargi] if mode == 1 else [])
         ctx.save_for_backward(*saved)
         ctx.meta = (float(h), int(mode), tuple(X.shape), (hy, wy))
@@ -90,39 +92,39 @@ class _ContextualCX(torch.autograd.Function):
         # no host read-back, the backward pass only enqueues
         gs = (gscale * gout.detach().to(gscale.dtype)).contiguous()
         R = min(ROW_BLOCK, (Nx + 63) // 64 * 64)
-        S = torch.empty((1, R, hy, wy), **f32)
-        blk = torch.zeros((C, R), **f32)
-        dST = torch.empty((1, Ny, R // 32, 32), **f32)                       # [Ny][R] as an image of R "pixels"
-        tt, qq = (torch.empty(R, **f32), torch.empty(R, **f32)) if mode == 1 else (None, None)
+        S = torch.empty((B, R, hy, wy), **f32)
+        blk = torch.zeros((B, C, 1, R), **f32)
+        dST = torch.empty((B, Ny, R // 32, 32), **f32)                       # [Ny][R] per image, as an image of R "pixels"
+        tt, qq = (torch.empty((B, R), **f32), torch.empty((B, R), **f32)) if mode == 1 else (None, None)
         dXn = torch.empty_like(Xn)
-        for b in range(B):
-            y_img = Yn[b].view(1, C, hy, wy)
-            y_t = Yn[b].t().contiguous().view(Ny, 1, C)                      # K-major weights of d Xn = Yn dS^T
-            for i0 in range(0, Nx, R):
-                rows = min(R, Nx - i0)
-                _s_block(Xn[b], y_img, i0, rows, R, S, blk)
-                sl = slice(i0, i0 + rows)
-                if mode == 1:
-                    _lib.check(lib.dvc_cx_rows_tq(_p(S), _p(a[b, sl]), _p(l[b, sl]), _ip(cargi[b]), rows, Ny, i0, h, _p(tt), _p(qq),
-                                                  st), "dvc_cx_rows_tq")
-                _lib.check(lib.dvc_cx_ds(_p(S), _p(a[b, sl]), _p(l[b, sl]), _p(r[b, sl]), _p(e[b, sl]), _ip(jstar[b, sl]),
-                                         None if cargi is None else _ip(cargi[b]), _p(tt), _p(qq), _p(gs[b:b + 1]),
-                                         1.0, mode, rows, Ny, i0, R, h, None, _p(dST), st), "dvc_cx_ds")
-                dxb = ops.conv2d(dST, y_t, None, ksize=1, pad=0)              # [1, C, R/32, 32]
-                dXn[b][:, i0:i0 + rows] = dxb.view(C, R)[:, :rows]
+        y_img = Yn.view(B, C, hy, wy)
+        y_t = Yn.transpose(1, 2).contiguous().view(B, Ny, 1, C)              # K-major per-image filters of d Xn = Yn dS^T
+        S_bs = R * Ny
+        for i0 in range(0, Nx, R):
+            rows = min(R, Nx - i0)
+            _s_block(Xn, y_img, i0, rows, R, S, blk)
+            sl = slice(i0, i0 + rows)
+            if mode == 1:
+                _lib.check(lib.dvc_cx_rows_tq(_p(S), B, S_bs, Nx, R, _p(a[:, sl]), _p(l[:, sl]), _ip(cargi), rows, Ny, i0, h, _p(tt),
+                                              _p(qq), st), "dvc_cx_rows_tq")
+            _lib.check(lib.dvc_cx_ds(_p(S), B, S_bs, Nx, R, _p(a[:, sl]), _p(l[:, sl]), _p(r[:, sl]), _p(e[:, sl]), _ip(jstar[:, sl]),
+                                     None if cargi is None else _ip(cargi), _p(tt), _p(qq), _p(gs), 1.0, mode, rows, Ny, i0, R, h,
+                                     None, _p(dST), st), "dvc_cx_ds")
+            dxb = ops.conv2d(dST, y_t, None, ksize=1, pad=0)                  # [B, C, R/32, 32]
+            dXn[:, :, i0:i0 + rows] = dxb.view(B, C, R)[:, :, :rows]
         dX = torch.empty_like(Xn)
         _lib.check(lib.dvc_cx_normalize_bwd(_p(Xn), _p(normX), _p(dXn), B, C, Nx, float(EPS64), _p(dX), st), "dvc_cx_normalize_bwd")
         return dX.view(xshape), None, None, None, None
 
 
-def _s_block(Xn_b, y_img, i0, rows, R, S, blk):
-    """S[i, :] = sum_c Xn[c, i0 + i] Yn[c, :] for a block of R rows (zero rows beyond `rows`), on the 1x1-conv engine.
-    `blk` [C, R]: the caller's staging buffer for the block's columns (stream-ordered reuse, no allocation per block)."""
-    C = Xn_b.shape[0]
+def _s_block(Xn, y_img, i0, rows, R, S, blk):
+    """S[b, i, :] = sum_c Xn[b, c, i0 + i] Yn[b, c, :] for a block of R rows (zero rows beyond `rows`) of every image of the batch:
+    ONE launch of the 1x1-conv engine with per-image filters.  `blk` [B, C, 1, R]: the caller's staging buffer for the blocks'
+    columns (stream-ordered reuse, no allocation per block)."""
     if rows < R:
-        blk[:, rows:].zero_()
-    blk[:, :rows].copy_(Xn_b[:, i0:i0 + rows])
-    ops.conv2d(y_img, blk.view(C, 1, R), None, ksize=1, pad=0, out=S)
+        blk[..., rows:].zero_()
+    blk[:, :, 0, :rows].copy_(Xn[:, :, i0:i0 + rows])
+    ops.conv2d(y_img, blk, None, ksize=1, pad=0, out=S)
 
 
 def _check(X_features, Y_features):

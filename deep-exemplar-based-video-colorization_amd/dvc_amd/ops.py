@@ -135,27 +135,34 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
            act=ACT_NONE, act_slope=0.0, act_slope_t=None, in_scale=None, in_shift=None, in_slope_t=None,
            residual=None, out=None, out_batch_stride=0, cfg=-1, split_k=0):
     """dvc_conv2d.  x: [N,Cin,H,W]; w_packed: [Cin, k*k, Cout].  `out` may be a channel slice view's
-    base pointer tensor (pass `out_batch_stride` in elements)."""
+    base pointer tensor (pass `out_batch_stride` in elements).
+    w_packed [N, Cin, k*k, Cout]: per-image filters (DvcConvDesc.w_batch_stride) — with ksize 1 a batched GEMM
+    out[n] = w_packed[n]^T x[n], one launch for the whole batch (the training-side N x N products)."""
     lib = _lib.load()
     for t, nm in ((x, "x"), (w_packed, "w_packed"), (bias, "bias"), (in_scale, "in_scale"),
                   (in_shift, "in_shift"), (in_slope_t, "in_slope"), (act_slope_t, "act_slope"),
                   (residual, "residual")):
         _need(t, nm)
     N, Cin, H, W = x.shape
-    assert w_packed.shape[0] == Cin and w_packed.shape[1] == ksize * ksize, (w_packed.shape, Cin, ksize)
-    Cout = w_packed.shape[2]
+    w_bs = 0
+    if w_packed.dim() == 4:
+        assert w_packed.shape[0] == N, (w_packed.shape, x.shape)
+        w_bs = w_packed[0].numel()
+    wshape = tuple(w_packed.shape[-3:])
+    assert wshape[0] == Cin and wshape[1] == ksize * ksize, (w_packed.shape, Cin, ksize)
+    Cout = wshape[2]
     OH, OW = conv_out_hw(H, W, ksize, stride, dil, pad, in_up, in_sub)
     if out is None:
         out = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
     d = DvcConvDesc(N, Cin, H, W, Cout, ksize, stride, dil, pad, pad_mode, in_up, in_sub, act,
-                    float(act_slope), 1 if in_slope_t is not None else 0, cfg, split_k, 0, out_batch_stride, 0)
+                    float(act_slope), 1 if in_slope_t is not None else 0, cfg, split_k, 0, out_batch_stride, 0, 0, w_bs)
     if residual is not None:
         assert tuple(residual.shape) == (N, Cout, OH, OW), (residual.shape, (N, Cout, OH, OW))
     if _autotune and cfg == -1 and split_k == 0:
         # (no N in the key and a single-image descriptor for the timing: the library plans per image, so that a batch is
         # bit-identical to single-image calls — the tuned choice must not depend on the batch size either)
         key = (Cin, H, W, Cout, ksize, stride, dil, pad, pad_mode, in_up, in_sub, in_scale is not None,
-               in_slope_t is not None, residual is not None, act, x.device.index)
+               in_slope_t is not None, residual is not None, act, x.device.index, w_packed.dim() == 4)
         best = _tuned.get(key)
         if best is None:
             d1 = DvcConvDesc.from_buffer_copy(d)

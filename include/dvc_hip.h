@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 13
+#define DVC_ABI_VERSION 14
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -90,6 +90,11 @@ typedef struct DvcConvDesc {
     int64_t y_batch_stride;     /* elements; 0 => Cout*OH*OW  (lets y be a channel slice) */
     int64_t res_batch_stride;   /* elements; 0 => Cout*OH*OW */
     int32_t flags;              /* DVC_CONV_* bits (0 = none) */
+    int64_t w_batch_stride;     /* dvc_conv2d only, elements; 0 => the N images share one filter set (a convolution); != 0 =>
+                                   image n uses w_packed + n * w_batch_stride: with ksize 1 that is a BATCHED GEMM
+                                   y[n] = w[n]^T x[n] (K = Cin, M = Cout, N = H*W) — the N x N affinity products of the
+                                   training-side callers (models/ContextualLoss.py:97-126, train.py:402-427), one launch for
+                                   the whole batch.  Multiple of 4 (16-byte aligned slices); general engine only (cfg < 32) */
 } DvcConvDesc;
 /* dvc_conv2d_winograd only: when the layer is split over input channels (dvc_conv2d_winograd_split > 1), leave the partial
  * sums [split][N][Cout][OH*OW] in the workspace instead of launching the reduce — bias, activation and `y` are then NOT applied /
@@ -346,33 +351,38 @@ int dvc_corr_fwd_bf16(const void* theta_bf16_pc, const void* phi_bf16_pc, const 
  * train.py:649-668 on relu3_1 / relu4_1 / relu5_1 features of the prediction and of the exemplar).  Per image, X = predicted,
  * Y = exemplar features [C][N]:   mu = mean_j Y;  Xn, Yn = (. - mu) / (||.||_C + eps);  S = Xn^T Yn;  d = 1 - S;
  * a_i = min_j d_ij + 1e-5;  A = softmax_j((1 - d / a_i) / h);  CX = mean_i max_j A_ij  (_forward)  |  mean_j max_i A_ij;
- * loss = -log CX.  The GEMMs run as 1x1 convolutions (dvc_conv2d) from the host (dvc_amd/contextual.py) in blocks of rows
- * of S; these entries are the pieces in between, forward and backward (gradient w.r.t. X; Y is data, as in train.py). */
+ * loss = -log CX.  The GEMMs run as 1x1 convolutions with per-image filters — batched GEMMs, DvcConvDesc::w_batch_stride —
+ * (dvc_conv2d) from the host (dvc_amd/contextual.py) in blocks of rows of S, all images of the batch per launch; these entries are the pieces in between, forward and backward (gradient w.r.t. X; Y is data, as in train.py). */
 /* x [B][C][P] -> out = (x - mean) / (||x - mean||_C + eps).  centre == 0: no mean.  mean_in != NULL: use it ([B*C], e.g. the
  * exemplar's, ContextualLoss.py:49-51); otherwise the own per-channel mean is computed into mean_out.  norm_out [B][P] (or
  * NULL) receives ||x - mean||_C (needed by dvc_cx_normalize_bwd). */
 int dvc_cx_prepare(const float* x, const float* mean_in, int32_t centre, int32_t B, int32_t C, int32_t P, float eps,
                    float* mean_out, float* norm_out, float* out, dvcStream stream);
-/* S [rows][N] (a block of rows of Xn^T Yn) -> per row: a = (1 - max_j S) + 1e-5, jstar = arg max_j S (lowest index on ties),
- * l = sum_j w, r = max_j A = w_jstar / l, e = sum_j A_ij d_ij, with w = exp((1 - d / a) / h). */
-int dvc_cx_rows(const float* S, int32_t rows, int32_t N, float h, float* a, int32_t* jstar, float* l, float* r, float* e,
-                dvcStream stream);
+/* The entries below take a BATCH of nb images in one launch (r04; the products in between are batched GEMMs, DvcConvDesc::
+ * w_batch_stride): S_bs = elements between the images' S blocks, row_bs = elements between their per-row arrays (a, jstar, l,
+ * r, e: [nb][Nx] slices starting at the block's first row), tq_bs = between their t / q arrays; cmax / cargi are [nb][N],
+ * gscale / loss [nb], dST [nb][N][ld_t]. */
+/* S [nb][rows][N] (a block of rows of Xn^T Yn per image) -> per row: a = (1 - max_j S) + 1e-5, jstar = arg max_j S (lowest index
+ * on ties), l = sum_j w, r = max_j A = w_jstar / l, e = sum_j A_ij d_ij, with w = exp((1 - d / a) / h). */
+int dvc_cx_rows(const float* S, int32_t nb, int64_t S_bs, int64_t row_bs, int32_t rows, int32_t N, float h, float* a, int32_t* jstar,
+                float* l, float* r, float* e, dvcStream stream);
 /* ContextualLoss only: running column maxima of A over row blocks (cmax initialised below 0, cargi = the winning global row,
  * row0 = global index of the block's first row). */
-int dvc_cx_colmax(const float* S, const float* a, const float* l, int32_t rows, int32_t N, int32_t row0, float h, float* cmax,
-                  int32_t* cargi, dvcStream stream);
-/* loss = -log(mean(v[0..n))),  gscale = d loss / d v_k = -1 / (n mean(v)) */
-int dvc_cx_finish(const float* v, int32_t n, float* loss, float* gscale, dvcStream stream);
+int dvc_cx_colmax(const float* S, int32_t nb, int64_t S_bs, int64_t row_bs, const float* a, const float* l, int32_t rows, int32_t N,
+                  int32_t row0, float h, float* cmax, int32_t* cargi, dvcStream stream);
+/* per image b of v [nb][n]: loss[b] = -log(mean(v[b])),  gscale[b] = d loss / d v_k = -1 / (n mean(v[b])) */
+int dvc_cx_finish(const float* v, int32_t nb, int32_t n, float* loss, float* gscale, dvcStream stream);
 /* ContextualLoss backward: per row i of the block, t = sum of A_ik over the columns k whose maximum sits in row i
  * (cargi[k] == row0 + i), q = the same sum weighted by d_ik. */
-int dvc_cx_rows_tq(const float* S, const float* a, const float* l, const int32_t* cargi, int32_t rows, int32_t N, int32_t row0,
-                   float h, float* t, float* q, dvcStream stream);
-/* d loss / d S for a block of rows, row-major (dS, may be NULL) and transposed (dST [N][ld_t], rows >= `rows` zero-filled:
+int dvc_cx_rows_tq(const float* S, int32_t nb, int64_t S_bs, int64_t row_bs, int64_t tq_bs, const float* a, const float* l,
+                   const int32_t* cargi, int32_t rows, int32_t N, int32_t row0, float h, float* t, float* q, dvcStream stream);
+/* d loss / d S for a block of rows, row-major (dS, may be NULL) and transposed (dST [nb][N][ld_t], rows >= `rows` zero-filled:
  * the K-major operand of d Xn = Yn dS^T).  mode 0 = ContextualLoss_forward, 1 = ContextualLoss (needs cargi, t, q).
- * gscale: device scalar from dvc_cx_finish; gout: the upstream gradient of this image's loss. */
-int dvc_cx_ds(const float* S, const float* a, const float* l, const float* r, const float* e, const int32_t* jstar,
-              const int32_t* cargi, const float* t, const float* q, const float* gscale, float gout, int32_t mode, int32_t rows,
-              int32_t N, int32_t row0, int32_t ld_t, float h, float* dS, float* dST, dvcStream stream);
+ * gscale: [nb] device values from dvc_cx_finish (times the upstream gradient of each image's loss); gout: a common factor. */
+int dvc_cx_ds(const float* S, int32_t nb, int64_t S_bs, int64_t row_bs, int64_t tq_bs, const float* a, const float* l, const float* r,
+              const float* e, const int32_t* jstar, const int32_t* cargi, const float* t, const float* q, const float* gscale,
+              float gout, int32_t mode, int32_t rows, int32_t N, int32_t row0, int32_t ld_t, float h, float* dS, float* dST,
+              dvcStream stream);
 /* backward of xn = xc / (||xc|| + eps) per position: dx = dxn / (n + eps) - xn (xn . dxn) / n. */
 int dvc_cx_normalize_bwd(const float* xn, const float* norm, const float* dxn, int32_t B, int32_t C, int32_t P, float eps,
                          float* dx, dvcStream stream);
