@@ -138,28 +138,47 @@ extern "C" int dvc_cx_rows(const float* S, int32_t nb, int64_t S_bs, int64_t row
 }
 
 // ---- ContextualLoss (max over ROWS for every column): running column maxima of A over the row blocks.
-// Thread = column; rows walked in order (coalesced along j), strict '>' keeps the lowest row index on ties.
+// Workgroup = 64 columns x 4 row groups (r04: one thread per column walking all rows serially left a 16-image batch with 96
+// workgroups of 1300-step latency chains); group g walks rows g, g + 4, ... in ascending order (strict '>' keeps its lowest
+// row on ties), the groups are combined through LDS: larger value, then LOWER row index — the result of the serial scan.
 __global__ __launch_bounds__(256) void cx_colmax_kernel(const float* __restrict__ S, long S_bs, long row_bs,
                                                         const float* __restrict__ a, const float* __restrict__ l, int rows, int N,
                                                         int i0, float h, float* __restrict__ cmax, int* __restrict__ cargi) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx;
+    const bool ok = j < N;
     S += (long)blockIdx.y * S_bs; a += (long)blockIdx.y * row_bs; l += (long)blockIdx.y * row_bs;
     cmax += (long)blockIdx.y * N; cargi += (long)blockIdx.y * N;
-    float best = cmax[j];
-    int bi = cargi[j];
-    for (int i = 0; i < rows; ++i) {
-        const float v = cx_w(S[(long)i * N + j], a[i], h) / l[i];
-        if (v > best) { best = v; bi = i0 + i; }
+    // (group 0 carries the running maximum of the earlier row blocks: their rows are lower, so they win ties below)
+    float best = (ok && g == 0) ? cmax[j] : -INFINITY;
+    int bi = (ok && g == 0) ? cargi[j] : 0x7fffffff;
+    if (ok)
+        for (int i = g; i < rows; i += 4) {
+            const float v = cx_w(S[(long)i * N + j], a[i], h) / l[i];
+            if (v > best) { best = v; bi = i0 + i; }
+        }
+    sv[g][tx] = best;
+    si[g][tx] = bi;
+    __syncthreads();
+    if (g == 0 && ok) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const float v = sv[k][tx];
+            const int vi = si[k][tx];
+            // (group 0's carried-in value may tie a later row's: the earlier block's row index is lower and is kept)
+            if (v > best || (v == best && vi < bi)) { best = v; bi = vi; }
+        }
+        cmax[j] = best;
+        cargi[j] = bi;
     }
-    cmax[j] = best;
-    cargi[j] = bi;
 }
 
 extern "C" int dvc_cx_colmax(const float* S, int32_t nb, int64_t S_bs, int64_t row_bs, const float* a, const float* l, int32_t rows,
                              int32_t N, int32_t row0, float h, float* cmax, int32_t* cargi, dvcStream stream) {
     DVC_REQUIRE(S && a && l && cmax && cargi && nb > 0 && nb < 65536 && rows > 0 && N > 0 && h > 0.f, "dvc_cx_colmax: bad argument");
-    hipLaunchKernelGGL(cx_colmax_kernel, dim3(cdiv(N, 256), nb), dim3(256), 0, (hipStream_t)stream, S, (long)S_bs, (long)row_bs, a, l,
+    hipLaunchKernelGGL(cx_colmax_kernel, dim3(cdiv(N, 64), nb), dim3(256), 0, (hipStream_t)stream, S, (long)S_bs, (long)row_bs, a, l,
                        rows, N, row0, h, cmax, cargi);
     DVC_CHECK_LAUNCH("dvc_cx_colmax");
     return 0;

@@ -379,6 +379,25 @@ def test_conv2d_winograd_dual(ops, N, CA, CB, Cout, H, W, upA, upB, act):
         ops.conv2d_winograd_dual(xA.cuda(), xB.cuda()[:, :, :-2].contiguous(), u, b, in_upA=upA, in_upB=upB)
 
 
+@pytest.mark.parametrize("B,K,M,H,W,split_k", [(4, 256, 320, 13, 24, 0), (3, 512, 1344, 27, 48, 0), (2, 96, 64, 9, 11, 2), (1, 64, 128, 8, 8, 0)])
+def test_conv2d_per_image_filters_is_a_batched_gemm(ops, B, K, M, H, W, split_k):
+    """DvcConvDesc.w_batch_stride (r04): a 1x1 "convolution" whose filters differ per image is the batched GEMM
+    out[b] = w[b]^T x[b] (K = Cin, M = Cout, N = H * W) — the N x N affinity products of the contextual losses
+    (models/ContextualLoss.py:97-126), ONE launch for the whole batch instead of one per image.  Against a float64 bmm and
+    against B single-image launches of the same engine (bit-identical: the plan is per image)."""
+    g = torch.Generator().manual_seed(B * 1000 + K)
+    x = torch.randn(B, K, H, W, generator=g).cuda()
+    w = (torch.randn(B, K, 1, M, generator=g) * 0.1).cuda()
+    got = ops.conv2d(x, w, None, ksize=1, pad=0, split_k=split_k)
+    ref = torch.bmm(w.view(B, K, M).double().transpose(1, 2), x.view(B, K, H * W).double()).view(B, M, H, W)
+    assert relerr(got, ref.cpu()) < 2e-5
+    for b in range(B):
+        one = ops.conv2d(x[b:b + 1].contiguous(), w[b].contiguous(), None, ksize=1, pad=0, split_k=split_k)
+        assert torch.equal(got[b:b + 1], one), b
+    with pytest.raises(RuntimeError, match="general engine"):
+        ops.conv2d(x, w, None, ksize=1, pad=0, cfg=36)
+
+
 def test_conv2d_channel_slice_output(ops):
     """y may be a channel slice of a wider tensor (WarpNet concat, NonlocalNet.py:464)."""
     g = torch.Generator().manual_seed(5)
