@@ -448,6 +448,8 @@ def main():
     multi = None
     if args.refs > 1 and args.lookahead > 0 and rank == 0 and not args.no_exemplar_cache:
         ref_seeds = [synth.EXEMPLAR_SEED, 3, 5, 11, 13, 17, 19, 23][:args.refs]
+        # (every launch from Python: with four correlations per front end a replayed front-end graph is 2 % SLOWER here —
+        # 626 vs 634-641 frame-colourisations/s, profiles/r04_refs_chain_probe.txt — its backlog of packets delays the chain)
         cc_m = ClipColorizer(*nets, temperature=1e-10)
         cc_m.set_exemplars([synth.synth_lab(sd_, H, W).to(device) for sd_ in ref_seeds])
         cc_m.clip(frames[:max(Wm, 2)], lookahead=args.lookahead)             # warm-up (autotune at batch R, stream pools)

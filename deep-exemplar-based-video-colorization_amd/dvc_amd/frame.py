@@ -242,7 +242,8 @@ class ClipColorizer:
     def _captured(self, kind, shape, device, slot, stream):
         # (everything a captured launch bakes in besides addresses: the frame geometry, the temperature — a kernel argument and
         # the choice of the correlation's instantiation — and the correlation precision)
-        key = (kind, tuple(shape), slot, float(self.temperature), getattr(self.warp, "corr_precision", "fp32"), device.index)
+        key = (kind, tuple(shape), slot, float(self.temperature), getattr(self.warp, "corr_precision", "fp32"), device.index,
+               self.n_refs)
         g = self._graphs.get(key)
         if g is None:
             # a superseded sequence keeps its activation arena alive: at most two (geometry, temperature, precision)
@@ -338,14 +339,15 @@ class ClipColorizer:
         use_graph = self.graph if graph is None else bool(graph)
         multi = self.n_refs > 1
         if multi:
-            # R references in one pass: the frames are single images, every per-frame result carries R images; the captured
-            # sequences hold one image per slot, so this mode issues its launches from Python
+            # R references in one pass: the frames are single images, every per-frame result carries R images.  The look-ahead
+            # front ends can be replayed (a slot holds one frame and R correlations' partial states); the chain is launched
+            # kernel by kernel — the pipelined driver's default split (`graph_parts == "front"`)
             if frame_propagate:
                 raise ValueError("ClipColorizer.clip: frame_propagate uses the clip's first frame as THE exemplar; it has no "
                                  "multi-reference form (test.py:50 ignores the reference file in that mode)")
             if any(f.shape[0] != 1 for f in frames_lab):
                 raise ValueError("ClipColorizer.clip: multi-reference mode takes [1,3,H,W] frames")
-            use_graph, front_batch = False, 1
+            use_graph, front_batch = use_graph and self.graph_parts == "front" and lookahead > 0 and len(frames_lab) >= 2, 1
         if use_graph and int(front_batch) > 1:
             raise ValueError("ClipColorizer.clip: front_batch > 1 is not available with graph=True (a captured front end "
                              "holds one frame per slot); pass graph=False or front_batch=1")
@@ -474,22 +476,23 @@ class ClipColorizer:
             slot = slots[t % L]
             cur.wait_event(events.pop(t))
             with torch.cuda.stream(cur):
-                cin = ops.pack_color_input(frames_lab[t], slot.warped, slot.sim, out=None if eager_color else chain.cin, **prev)
+                cin = ops.pack_color_input(self._rep(frames_lab[t]), slot.warped, slot.sim, out=None if eager_color else chain.cin,
+                                           **prev)
                 slot.consumed = torch.cuda.Event()
                 slot.consumed.record(cur)
                 if eager_color:
-                    ab = self.col(cin)
+                    ab = self._chain(cin)
                 else:
                     chain.seq.replay()
                     ab = chain.ab.clone()
-                prev = dict(last_l=frames_lab[t], last_ab=ab)
+                prev = dict(last_l=self._rep(frames_lab[t]), last_ab=ab)
                 if on_frame is not None:
                     on_frame(t, frames_lab[t], ab)
             outs.append(ab)
             if t + L < T:
                 launch_front(t + L)
         with torch.cuda.stream(cur):
-            last = torch.cat((frames_lab[-1][:, 0:1], outs[-1]), dim=1)
+            last = torch.cat((self._rep(frames_lab[-1])[:, 0:1], outs[-1]), dim=1)
         caller.wait_stream(cur)
         for s in side:
             caller.wait_stream(s)

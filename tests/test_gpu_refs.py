@@ -108,6 +108,16 @@ def test_references_in_one_pass_equal_sequential_runs_and_the_oracle(H, W, R, nf
     # deterministic; a single exemplar afterwards returns the driver to the ordinary mode
     again = multi.clip(dev_frames, lookahead=2)
     assert all(torch.equal(a, b) for a, b in zip(again, got))
+    # the look-ahead front ends replayed as hipGraphs (one frame + R correlations per captured slot): the same bits, also
+    # after the references are replaced by others of the same geometry (the captured sequences read the refreshed cache)
+    gm = ClipColorizer(vgg, warp, col, temperature=T, graph=True)
+    gm.set_exemplars([b.cuda() for b in IBs])
+    assert all(torch.equal(a, b) for a, b in zip(gm.clip(dev_frames, lookahead=2), got))
+    assert any(k[0] == "front" and k[-1] == R for k in gm._graphs), "multi-reference front ends were not captured"
+    swapped = [b.cuda() for b in reversed(IBs)]
+    gm.set_exemplars(swapped)
+    multi.set_exemplars(swapped)
+    assert all(torch.equal(a, b) for a, b in zip(gm.clip(dev_frames, lookahead=2), multi.clip(dev_frames, lookahead=2)))
     multi.set_exemplar(IBs[0].cuda())
     assert multi.n_refs == 1 and tuple(multi.clip(dev_frames[:2])[0].shape) == (1, 2, H, W)
     with pytest.raises(ValueError, match="frame_propagate"):
