@@ -234,6 +234,7 @@ class ClipColorizer:
         """Install an exemplar cache received from another rank (inverse of exemplar_cache_tensors)."""
         tensors = list(tensors)
         self.IB_lab = IB_lab
+        self.n_refs = 1                 # (one exemplar per image of the batch, as after set_exemplar)
         self.features_B = None          # not needed once the exemplar side is cached
         new = ((tensors[0], tensors[1]), tensors[2]) if len(tensors) == 3 else (tensors[0], tensors[1])
         self.ex_cache = self._install_cache(self.ex_cache, new)
@@ -283,7 +284,9 @@ class ClipColorizer:
         return self._ensure_streams(2)[1][0]
 
     def frame(self, IA_lab, IA_last_lab, graph=None):
-        """One frame_colorization call (the per-frame API of test.py:85): returns (ab, warped Lab)."""
+        """One frame_colorization call (the per-frame API of test.py:85): returns (ab, warped Lab).
+        In multi-reference mode (set_exemplars) `IA_lab` is the one frame, `IA_last_lab` the R previous [L, ab] tensors
+        [R,3,H,W]; returns (ab [R,2,H,W], warped Lab [R,3,H,W]); launches are issued from Python (`graph` is not used)."""
         if self.n_refs > 1:     # one frame against the R references: IA_last_lab [R,3,H,W] -> (ab [R,2,H,W], warped [R,3,H,W])
             IA_lab = IA_lab.detach().contiguous().float()
             warped, sim, _ = warp_color(IA_lab[:, 0:1], self.IB_lab, None, self.vgg, self.warp, self.col, 0,
