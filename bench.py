@@ -252,6 +252,9 @@ def main():
     ap.add_argument("--min-timed-s", type=float, default=0.5,
                     help="the K-step clip is repeated until at least this much GPU work has been timed (>= 3 repeats); the line "
                          "reports the median repeat with p10 / p90")
+    ap.add_argument("--clips", type=int, default=4,
+                    help="B of the batched-clips leg (config.batched_clips: frame t of B independent clips, each with its own "
+                         "exemplar, per step — the serving form of the path; batch-aware launch plan); 0 skips the leg")
     ap.add_argument("--refs", type=int, default=4,
                     help="R of the multi-reference leg (config.multi_reference: the same clip against R exemplars in one pass, "
                          "test.py:169-181); 0 skips the leg")
@@ -463,6 +466,26 @@ def main():
                  "note": "the K timed frames against R exemplars in one pass (ClipColorizer.set_exemplars): one VGG19 + WarpNet "
                          "front end per frame, R fused correlations, ColorVidNet at batch R with a batch-aware launch plan; "
                          "compare frame_colorizations_per_s with `value` (R passes, one reference each)"}
+    # ... and B independent clips in lock step (serving): every step colourises frame t of B clips, each against its own exemplar;
+    # front ends and chain at batch B, planned for the batch (ClipColorizer(batch_plan=True))
+    batched = None
+    if args.clips > 1 and args.lookahead > 0 and rank == 0 and not args.no_exemplar_cache and (H, W) == (216, 384):
+        Bc = args.clips
+        cc_b = ClipColorizer(*nets, temperature=1e-10, batch_plan=True)
+        cc_b.set_exemplar(torch.cat([synth.synth_lab(synth.EXEMPLAR_SEED + 10 * c, H, W) for c in range(Bc)]).to(device))
+        bframes = [torch.cat([synth.synth_lab(synth.FRAME_SEED0 + 1000 * c + i, H, W) for c in range(Bc)]).to(device)
+                   for i in range(K + max(Wm, 2))]
+        cc_b.clip(bframes[:max(Wm, 2)], lookahead=args.lookahead)
+
+        def batched_clip():
+            return cc_b.clip(bframes[max(Wm, 2):], lookahead=args.lookahead)[-1]
+        t_b, ab_b = median_s(batched_clip, side_reps)
+        assert torch.isfinite(ab_b).all() and tuple(ab_b.shape) == (Bc, 2, H, W)
+        batched = {"B": Bc, "frames_per_s": round(Bc * K / t_b, 3), "ms_per_step": round(t_b / K * 1e3, 4),
+                   "note": "frame t of B independent clips per step, each clip with its own exemplar (the batched form of "
+                           "frame_colorization, train.py:402 calls it with B = 16): front ends and ColorVidNet chain at batch B with the "
+                           "batch-aware launch plan; per-clip results equal the single-clip driver's to fp32 rounding of the summation "
+                           "order (tests/test_gpu_refs.py)"}
     last = last_timed
     t = torch.tensor(rep_s, device=device, dtype=torch.float64)
     if use_dist:
@@ -581,6 +604,7 @@ def main():
                                    (graph_note or "every kernel launched from Python"),
                        "per_frame_api_frames_per_s": None if seq_fps is None else round(seq_fps, 3),
                        "eager_launch_clip_driver_frames_per_s": None if eager_fps is None else round(eager_fps, 3),
+                       "batched_clips": batched,
                        "multi_reference": None if multi is None else dict(
                            multi, speedup_vs_one_pass_per_reference=round(multi["frame_colorizations_per_s"] / (fps / n_gpus), 3))},
             "roofline": roof,

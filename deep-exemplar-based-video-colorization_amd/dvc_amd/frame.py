@@ -101,11 +101,16 @@ class ClipColorizer:
     `graph_parts`).  Needs the exemplar cache (the captured front end reads the cached exemplar side at fixed addresses;
     `set_exemplar` refreshes those buffers in place for the next clip)."""
 
-    def __init__(self, vggnet, nonlocal_net, colornet, temperature=1e-10, cache_exemplar=True, graph=False):
+    def __init__(self, vggnet, nonlocal_net, colornet, temperature=1e-10, cache_exemplar=True, graph=False, batch_plan=False):
         self.vgg, self.warp, self.col = vggnet, nonlocal_net, colornet
         self.temperature = temperature
         self.cache_exemplar = cache_exemplar
         self.graph = bool(graph)
+        # batch_plan=True (serving many clips at once: `clip` takes [B,3,H,W] frames = frame t of B independent clips, each with
+        # its own exemplar in `set_exemplar(IB [B,3,H,W])`): the Winograd launches of the front ends and of the chain are planned
+        # for the whole batch (ops.batch_plan / DVC_CONV_BATCH_PLAN) instead of per image — more frames/s, results deterministic
+        # per B but equal to the single-clip runs only to fp32 rounding of the summation order (off: bit-identical to them)
+        self.batch_plan = bool(batch_plan)
         # which sequences the PIPELINED driver replays: "front" (default) = the look-ahead front ends, with the ColorVidNet
         # chain launched kernel by kernel on the high-priority stream.  Measured on the MI355X (profiles/
         # r03_graph_overlap_probe.txt): a replayed graph puts its whole backlog of packets into its hardware queue at once,
@@ -188,7 +193,7 @@ class ClipColorizer:
     def _chain(self, cin):
         """The ColorVidNet chain; in multi-reference mode the R recurrences advance in lock step as ONE batch, planned as a
         batch (DVC_CONV_BATCH_PLAN)."""
-        if self.n_refs > 1:
+        if self.n_refs > 1 or (self.batch_plan and cin.shape[0] > 1):
             with ops.batch_plan(True):
                 return self.col(cin)
         return self.col(cin)
@@ -339,7 +344,7 @@ class ClipColorizer:
         frames_lab = [f.detach().contiguous().float() for f in frames_lab]
         if not frames_lab:
             return []
-        use_graph = self.graph if graph is None else bool(graph)
+        use_graph = (self.graph if graph is None else bool(graph)) and not self.batch_plan      # (batch-planned launches: eager)
         multi = self.n_refs > 1
         if multi:
             # R references in one pass: the frames are single images, every per-frame result carries R images.  The look-ahead
@@ -365,9 +370,10 @@ class ClipColorizer:
                     ab, _ = self._frame_graph(IA_lab, prev)
                 else:
                     IA_l = IA_lab[:, 0:1]
-                    warped, sim, _ = warp_color(IA_l, self.IB_lab, self.features_B, self.vgg, self.warp, self.col, 0,
-                                                temperature=self.temperature, exemplar_cache=self.ex_cache,
-                                                defer_merge=ops.fold_merge())
+                    with ops.batch_plan(self.batch_plan):
+                        warped, sim, _ = warp_color(IA_l, self.IB_lab, self.features_B, self.vgg, self.warp, self.col, 0,
+                                                    temperature=self.temperature, exemplar_cache=self.ex_cache,
+                                                    defer_merge=ops.fold_merge())
                     ab = self._chain(ops.pack_color_input(self._rep(IA_lab), warped, sim, **prev))
                 prev = dict(last_l=self._rep(IA_lab), last_ab=ab)
                 outs.append(ab)
@@ -397,9 +403,10 @@ class ClipColorizer:
             with torch.cuda.stream(s):
                 fr = [frames_lab[t] for t in batches[bi]]
                 IA_lab = fr[0] if len(fr) == 1 else torch.cat(fr, dim=0)
-                warped, sim, _ = warp_color(IA_lab[:, 0:1], self.IB_lab, self.features_B, self.vgg, self.warp,
-                                            self.col, 0, temperature=self.temperature,
-                                            exemplar_cache=self.ex_cache, defer_merge=ops.fold_merge() and nb == 1)
+                with ops.batch_plan(self.batch_plan):
+                    warped, sim, _ = warp_color(IA_lab[:, 0:1], self.IB_lab, self.features_B, self.vgg, self.warp,
+                                                self.col, 0, temperature=self.temperature,
+                                                exemplar_cache=self.ex_cache, defer_merge=ops.fold_merge() and nb == 1)
                 ev = torch.cuda.Event()
                 ev.record(s)
             fronts[bi] = (IA_lab, warped, sim, ev)

@@ -125,6 +125,44 @@ def test_references_in_one_pass_equal_sequential_runs_and_the_oracle(H, W, R, nf
         multi.clip(dev_frames[:2], frame_propagate=True)
 
 
+def test_batched_clips_in_lock_step():
+    """The serving form: `clip` with [B,3,H,W] frames = frame t of B independent clips, each with its own exemplar
+    (set_exemplar(IB [B,3,H,W])).  With the default per-image plan every clip's predictions are BIT-IDENTICAL to the
+    single-clip driver's; with ClipColorizer(batch_plan=True) (front ends and chain planned for the batch) they agree to fp32
+    rounding of the summation order (stated tolerance 2.5e-4) and stay within 1e-3 of the oracle per clip."""
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    from oracle import dvc_oracle as O
+    H, W, T, B, nf = 48, 80, 1e-10, 3, 4
+    _oracle_threads()
+    (vgg, warp, col), sd = _nets()
+    IBs = [synth.synth_lab(s, H, W) for s in REF_SEEDS[:B]]
+    clips = [[synth.synth_lab(synth.FRAME_SEED0 + 100 * c + i, H, W) for i in range(nf)] for c in range(B)]
+    steps = [torch.cat([clips[c][i] for c in range(B)]).cuda() for i in range(nf)]
+    outs = {}
+    for plan in (False, True):
+        cc = ClipColorizer(vgg, warp, col, temperature=T, batch_plan=plan)
+        cc.set_exemplar(torch.cat(IBs).cuda())
+        outs[plan] = cc.clip(steps, lookahead=2)
+        assert all(tuple(o.shape) == (B, 2, H, W) for o in outs[plan])
+        seq = cc.clip(steps, lookahead=0)
+        assert all(torch.equal(a, b) for a, b in zip(outs[plan], seq))
+    worst = 0.0
+    for c in range(B):
+        one = ClipColorizer(vgg, warp, col, temperature=T)
+        one.set_exemplar(IBs[c].cuda())
+        want = one.clip([f.cuda() for f in clips[c]], lookahead=0)
+        with torch.no_grad():
+            ora = O.colorize_clip(clips[c], IBs[c], *sd, temperature=T)
+        for i in range(nf):
+            assert torch.equal(outs[False][i][c:c + 1], want[i]), (c, i)
+            d = (outs[True][i][c:c + 1] - want[i]).abs().max().item()
+            worst = max(worst, d)
+            assert d <= PER_R_TOL, (c, i, d)
+            assert (outs[True][i][c:c + 1].cpu() - ora[i]).abs().max().item() <= NORTH_STAR_TOL
+    report(f"batched clips {H}x{W} B={B}: per-image plan bit-identical to the single-clip driver; batch-aware plan within {worst:.2e}")
+
+
 def test_pack_color_input_with_one_frame_for_all_references():
     """dvc_pack_color_input with a NEGATIVE batch stride (the C-ABI's spelling of stride 0; 0 itself means "densely packed"):
     one frame's luminance plane for the R images of the batch.  (r04: the first version passed the 0 of an expanded tensor,
