@@ -538,7 +538,8 @@ class ClipColorizer:
             for _, ab in pending:
                 ab.record_stream(ts)
             with torch.cuda.stream(ts):
-                out, _ = tail.frames_tail([frames_lab_large[t] for t in idx], [ab[r:r + 1] for _, ab in pending for r in range(R)],
+                out, _ = tail.frames_tail([frames_lab_large[t] for t in idx],
+                                          [ab if R == 1 else ab[r:r + 1] for _, ab in pending for r in range(R)],
                                           wls_filter_on, lambda_value, sigma_color)
             if R == 1:
                 for t, r in zip(idx, out):

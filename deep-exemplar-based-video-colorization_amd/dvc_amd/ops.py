@@ -214,7 +214,8 @@ class batch_plan:
     workgroups fill the chip together, so under-filled layers drop (part of) their split over input channels — no partial
     sums, no reduce.  Results are deterministic per batch size but no longer bit-identical to single-image calls (the fp32
     summation order over input channels follows the split).  Off by default: everywhere else a batch of N equals N calls bit
-    for bit.  Used by the multi-reference clip driver (ClipColorizer.clip_refs), whose R recurrences must run together."""
+    for bit.  Used by the multi-reference pass (ClipColorizer.set_exemplars -> clip), whose R recurrences must run together, and by
+    ClipColorizer(batch_plan=True) for batches of independent clips."""
 
     def __init__(self, on=True):
         self.on = bool(on)
@@ -768,6 +769,10 @@ def _merge_pack(lib, IA_lab, part, IA_last_lab, last_l, last_ab, out, want_warpe
         raise RuntimeError(f"dvc_amd: pack_color_input: frame {tuple(IA_lab.shape)} does not fit the correlation's {len(part.bufs)} x "
                            f"{part.h} x {part.w} partial states")
     HW = H * W
+    # (the fused launch moves float4 pieces: a view whose planes do not start on 16 bytes — an odd storage offset — is copied
+    # once; fresh allocations and whole tensors never are)
+    al = lambda t: t if t is None or (t.data_ptr() % 16 == 0 and (t.stride(0) * 4) % 16 == 0) else t.clone(memory_format=torch.contiguous_format)  # noqa: E731
+    IA_lab, IA_last_lab, last_l, last_ab = al(IA_lab), al(IA_last_lab), al(last_l), al(last_ab)
     ia, ia_bs = _plane(IA_lab, 0, "IA_lab")
     if IA_last_lab is not None:
         ll, ll_bs = _plane(IA_last_lab, 0, "IA_last_lab")

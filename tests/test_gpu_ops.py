@@ -961,6 +961,12 @@ def test_corr_merge_folded_into_pack_color_input(ops, h, w, B, T):
         part1 = ops.corr_fwd(th[:1], ph, bl, T, h, w, defer_merge=True)
         rep = IA[:1].expand(B, -1, -1, -1)
         assert torch.equal(ops.pack_color_input(rep, part1, None, last), ops.pack_color_input(rep, ref1["y_up"], ref1["sim_up"], last))
+    # a view whose planes do not start on 16 bytes (odd storage offset) is copied once instead of failing the launch's alignment check
+    flat = torch.zeros(1 + IA.numel(), device="cuda")
+    odd = flat[1:].view_as(IA)
+    odd.copy_(IA)
+    assert odd.data_ptr() % 16 != 0
+    assert torch.equal(ops.pack_color_input(odd, part, None, last), want)
     # WTA / taps keep the materialised path
     assert isinstance(ops.corr_fwd(th, ph, bl, T, h, w, wta_scale=0.5, defer_merge=True), dict)
     assert isinstance(ops.corr_fwd(th, ph, bl, T, h, w, want_argmax=True, defer_merge=True), dict)
