@@ -24,8 +24,8 @@ fi
 if [[ $what == all || $what == prof ]]; then
   rm -rf gpurun_out/prof
   export DVC_AUTOTUNE_CACHE=$PWD/gpurun_out/autotune.json
-  timeout 200 python bench.py --steps 5 --warmup 3 --no-cpu-baseline --refs 0 > /dev/null 2>&1   # fills the autotune cache
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o trace -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --refs 0 > gpurun_out/prof_bench.json 2> gpurun_out/prof.err
+  timeout 200 python bench.py --steps 5 --warmup 3 --no-cpu-baseline --refs 0 --clips 0 > /dev/null 2>&1   # fills the autotune cache
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o trace -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --refs 0 --clips 0 > gpurun_out/prof_bench.json 2> gpurun_out/prof.err
   echo "prof rc=$?"; cat gpurun_out/prof_bench.json
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
   [[ -n "$f" ]] && head -n 40 "$f"
