@@ -43,6 +43,7 @@ CORR_FLOPS = 2.0 * P * P * C + 2.0 * P * P * 3          # 13.92 GFLOP
 CORR_BYTES = 4.0 * (2 * P * C + 3 * P + 3 * P + P)      # 10.76 MB compulsory traffic
 PATH_FLOPS = 348.4e9                                     # minimal whole-path FLOPs / frame
 PEAK_F32_MFMA_TFLOPS = 157.3                             # MI355X_MICROARCH.md, fp32 matrix
+PEAK_BF16_MFMA_TFLOPS = 2500.0                           # dense bf16 matrix peak (never the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
 # HBM traffic of one corr_fwd_kernel launch at P=5184.  rocprofv3 --pmc cannot run inside this process, so this
 # is an OFFLINE measurement (tools/pmc_corr.sh -> tools/summarize_profiles.py), not a number of this run: the
@@ -192,6 +193,41 @@ def cpu_baseline(sd):
             "by_threads": {str(k): v for k, v in sorted(legs.items())}}
 
 
+def parity_block(cc, sd, device):
+    """Untimed: how far the TIMED engine is from the fp64 truth at the timed configuration, next to the reference-equivalent
+    CPU fp32 run against the same truth (SURVEY.md 7 hard part 1 / 8c: "must be <= the CPU figure").  One 216x384 frame as the
+    first frame of a clip (exemplar seed 2, frame seed 1000, the plain seed-0 weights `value` is measured with), T = 1e-10; the
+    oracle runs on the host CPU in fp32 and fp64 (checker only).  tests/test_gpu_nets.py asserts the same comparison."""
+    import numpy as np
+    from dvc_amd import ops, synth
+    from oracle import dvc_oracle as O
+    keep = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, host_cpus()[0])))
+    torch.set_flush_denormal(True)
+    try:
+        IB = synth.synth_lab(synth.EXEMPLAR_SEED, 216, 384)
+        fr = synth.synth_lab(synth.FRAME_SEED0, 216, 384)
+        z = torch.zeros_like(fr)
+        sd64 = tuple(O.to_dtype(s, torch.float64) for s in sd)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ab32 = O.frame_colorization(fr, IB, z, O.exemplar_features(IB, sd[0]), *sd, temperature=1e-10)[0]
+            ab64 = O.frame_colorization(fr.double(), IB.double(), z.double(), O.exemplar_features(IB.double(), sd64[0]), *sd64,
+                                        temperature=1e-10)[0]
+        t_cpu = time.perf_counter() - t0
+        ab, _ = cc.frame(fr.to(device), z.to(device), graph=False)
+        st = lambda e: {"max": float(e.max()), "q999": float(np.quantile(e.numpy(), 0.999)), "mean": float(e.mean())}   # noqa: E731
+        g, c = st((ab.double().cpu() - ab64).abs()), st((ab32.double() - ab64).abs())
+        return {"gpu_vs_fp64": {k: float("%.4g" % v) for k, v in g.items()}, "cpu32_vs_fp64": {k: float("%.4g" % v) for k, v in c.items()},
+                "gpu_over_cpu32": {k: round(g[k] / c[k], 3) for k in g}, "conv_algo": ops.conv_algo(),
+                "direct_layers": sorted(ops.direct_layers()) if ops.conv_algo() == "auto" else None,
+                "sample": "ab of one 216x384 frame (first frame of a clip, exemplar seed 2, frame seed 1000, plain seed-0 weights, "
+                          "T = 1e-10): |GPU fp32 - oracle fp64| and |oracle fp32 (= the reference's CPU run) - oracle fp64| over the "
+                          f"2 x 216 x 384 values; untimed, oracle on the host CPU ({t_cpu:.0f} s)"}
+    finally:
+        torch.set_num_threads(keep)
+
+
 def executed_matrix_flops(cc, frame, last):
     """(executed, direct-equivalent) matrix FLOPs of ONE frame as the HIP path runs it: every convolution launch of a per-frame
     call is recorded (ops.conv_record) and priced by the engine that ran it — direct implicit GEMM 2 k^2 Cin Cout OH OW, Winograd
@@ -215,6 +251,17 @@ def executed_matrix_flops(cc, frame, last):
     return executed + CORR_FLOPS, direct + CORR_FLOPS, len(rec)
 
 
+def torchrun_command(n, argv, port, environ=None):
+    """(argv, environment) of the N-rank launch `python bench.py --gpus N` performs on itself: one process per GPU under
+    torch.distributed.run on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve), the caller's own
+    flags passed through unchanged, dmabuf IPC for RCCL (the host driver supports no other)."""
+    environ = os.environ if environ is None else environ
+    env = dict(environ, HSA_ENABLE_IPC_MODE_LEGACY=environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return cmd, env
+
+
 def relaunch_under_torchrun(n):
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start N ranks ourselves."""
     import socket
@@ -222,9 +269,7 @@ def relaunch_under_torchrun(n):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd, env = torchrun_command(n, sys.argv[1:], port)
     log("[bench] launching", " ".join(cmd))
     return subprocess.call(cmd, env=env)
 
@@ -235,6 +280,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity block (GPU and CPU fp32 against the fp64 oracle)")
     ap.add_argument("--clock-warmup-s", type=float, default=0.5,
                     help="seconds of untimed load (the warm-up frames, repeated) before the W warm-up steps, so that the "
                          "timed region does not start on a ramping GPU clock; 0 disables")
@@ -434,6 +480,41 @@ def main():
         t_seq, last_seq = median_s(per_frame_loop, side_reps)
         seq_fps = K / t_seq
         assert torch.equal(last_seq, last_timed), "pipelined clip driver != per-frame loop"
+    # ... and through the reference's UNMODIFIED call pattern (test.py:57-96): `features_B` computed once by the caller, then
+    # `frame_colorization(IA_lab, IB_lab, I_last, features_B, vggnet, nonlocal_net, colornet, feature_noise=0, temperature=1e-10)`
+    # frame by frame with the same exemplar tensors — no ClipColorizer, no cache argument, every launch from Python.  The
+    # exemplar side is memoised behind the call (nets.WarpNet._memo_exemplar_side); with DVC_EXEMPLAR_MEMO=0 it is recomputed per
+    # frame as the reference does (timed next to it).
+    dropin = None
+    if args.lookahead > 0 and rank == 0 and args.corr == "fp32":
+        from models.FrameColor import frame_colorization
+        from utils.util import tensor_lab2rgb, uncenter_l
+        vggnet, nonlocal_net, colornet = nets
+        I_reference_lab = IB
+        I_reference_rgb = tensor_lab2rgb(torch.cat((uncenter_l(I_reference_lab[:, 0:1]), I_reference_lab[:, 1:3]), dim=1))
+        features_B = vggnet(I_reference_rgb, ["r12", "r22", "r32", "r42", "r52"], preprocess=True)
+
+        def reference_loop():
+            I_last_lab_predict = last
+            for i in range(Wm, Wm + K):
+                IA_lab = frames[i]
+                IA_l = IA_lab[:, 0:1, :, :]
+                I_current_ab_predict, _, _ = frame_colorization(IA_lab, I_reference_lab, I_last_lab_predict, features_B, vggnet,
+                                                                nonlocal_net, colornet, feature_noise=0, temperature=1e-10)
+                I_last_lab_predict = torch.cat((IA_l, I_current_ab_predict), dim=1)
+            return I_last_lab_predict
+        reference_loop()
+        t_drop, last_drop = median_s(reference_loop, side_reps)
+        drop_diff = (last_drop - last_timed).abs().max().item()
+        assert drop_diff <= 1e-4, f"unmodified reference loop != clip driver ({drop_diff})"
+        ops.set_exemplar_memo(False)
+        try:
+            reference_loop()
+            t_drop_nomemo, _ = median_s(reference_loop, max(1, min(side_reps, 3)))
+        finally:
+            ops.set_exemplar_memo(True)
+        dropin = {"frames_per_s": round(K / t_drop, 3), "exemplar_side_recomputed_per_frame_frames_per_s": round(K / t_drop_nomemo, 3),
+                  "bit_identical_to_clip_driver": bool(drop_diff == 0.0)}
     # ... and, when the timed region replayed captured launch sequences, the same K frames with every launch issued from
     # Python (what r01/r02 timed): reported next to `value`, and required to give the same predictions bit for bit
     eager_fps = None
@@ -534,6 +615,37 @@ def main():
         t_standalone = time_corr(False)      # fused kernel + its merge kernel
         t_corr = time_corr(True) if folded else t_standalone
         achieved = CORR_FLOPS / t_corr / 1e12
+        bf16_roof = None
+        if args.corr == "bf16":
+            # configs[4]: the correlation this run's frames went through is the bf16 candidate filter + exact fp32 re-scoring
+            # (csrc/corr_bf16.hip: two bf16 MFMA sweeps, then one wave per query re-scores its candidates in fp32), not
+            # corr_fwd_kernel — time THAT set of launches on the clip's own operands, against the bf16 matrix peak.  It is an
+            # exactness-preserving filter, not a bf16-rate kernel: no throughput claim rides on it.
+            th16 = warp.project("theta", warp.features(*[feature_normalize(t) for t in fA[1:]]), bf16=True)
+            ph16, bl16 = cc.ex_cache if isinstance(cc.ex_cache[0], tuple) else warp.exemplar_side(
+                cc.IB_lab, *[feature_normalize(t) for t in cc.features_B[1:]], bf16=True)
+
+            def time_bf16():
+                for _ in range(100 if P <= 6000 else 10):
+                    ops.corr_fwd_bf16(th16, ph16, bl16.view(1, 3, -1), 1e-10, H // 4, W // 4)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    ops.corr_fwd_bf16(th16, ph16, bl16.view(1, 3, -1), 1e-10, H // 4, W // 4)
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e-3 / reps
+            t16 = time_bf16()
+            bf16_roof = {"kernel": "corr_bf16 pass kernels (two bf16 MFMA sweeps) + fp32 re-scoring kernel + merge, all launches of "
+                                   "one dvc_corr_fwd_bf16 call", "bound": "mfma", "achieved": round(CORR_FLOPS / t16 / 1e12, 3),
+                         "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(CORR_FLOPS / t16 / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                         "avg_launch_us": round(t16 * 1e6, 2), "traffic": None,
+                         "note": "algorithmic 13.92 GFLOP of the stage / time of the whole launch set; the per-kernel split (sweeps vs "
+                                 "re-scoring) is in the committed rocprofv3 trace of this command, profiles/r05_bench_bf16_kernel_stats.csv; "
+                                 "an exactness-preserving candidate filter (results identical to the fp32 kernel's), not a bf16-rate "
+                                 "kernel: no throughput claim (DESIGN.md 4.1b)",
+                         "fp32_kernel_for_comparison": {"kernel": "corr_fwd_kernel", "avg_launch_us": round(t_corr * 1e6, 2),
+                                                        "frac_of_fp32_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)}}
         traffic, traffic_src = corr_traffic() if (H, W) == (216, 384) else (None, {"kind": "not measured at this size"})
         exec_flops, direct_flops, n_convs = executed_matrix_flops(cc, frames[Wm], torch.zeros_like(frames[Wm]))
         exec_tflops = exec_flops * fps / n_gpus / 1e12
@@ -563,9 +675,14 @@ def main():
                                                  "convolutions; counted here: %.1f) x frames/s - NOT a roofline fraction: the "
                                                  "Winograd layers execute 2.25x fewer multiplications" % (direct_flops / 1e9)}}
 
-    cpu = None
+    if rank == 0 and roof is not None and bf16_roof is not None:
+        roof = dict(bf16_roof, hbm_view=roof["hbm_view"], whole_path=roof["whole_path"])
+    cpu = parity = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd)
+        if (H, W) == (216, 384) and not args.no_parity:
+            parity = parity_block(cc, sd, device)
+            log(f"[bench] parity vs fp64: GPU {parity['gpu_vs_fp64']}  CPU fp32 {parity['cpu32_vs_fp64']}")
 
     if rank == 0:
         line = {
@@ -582,8 +699,11 @@ def main():
                        "bf16 MFMA candidate filter + exact fp32 re-scoring (configs[4])",
                        "exemplar_side": "recomputed per frame" if args.no_exemplar_cache else "cached per clip",
                        "conv_algorithm": {"auto": "Winograd F(2x2,3x3) on the fp32 matrix cores where ops.winograd_selected "
-                                                  "picks it (3x3 stride-1 layers with >= 13x24 outputs), direct "
-                                                  "implicit GEMM elsewhere; fp32 throughout",
+                                                  "picks it (3x3 stride-1 layers with >= 13x24 outputs, minus the layers of the "
+                                                  "error-aware engine map arch.DIRECT_LAYERS: %s), direct implicit GEMM elsewhere; "
+                                                  "fp32 throughout" % (",".join(sorted(ops.direct_layers())) or "none"),
+                                          "speed": "Winograd F(2x2,3x3) on every 3x3 stride-1 layer with >= 13x24 outputs (geometry "
+                                                   "rule only, no error-aware map)",
                                           "winograd": "Winograd F(2x2,3x3) on every eligible 3x3 layer",
                                           "direct": "direct implicit GEMM everywhere"}[ops.conv_algo()],
                        "conv_tile_choice": "static cost model" if args.no_autotune else
@@ -603,12 +723,20 @@ def main():
                                     "eager launches (fixed mode, no warm-up trial)") if use_graph else
                                    (graph_note or "every kernel launched from Python"),
                        "per_frame_api_frames_per_s": None if seq_fps is None else round(seq_fps, 3),
+                       "dropin_unmodified_frames_per_s": None if dropin is None else dropin["frames_per_s"],
+                       "dropin_unmodified": None if dropin is None else dict(
+                           dropin, note="the reference's own loop, test.py:57-96, verbatim: features_B computed by the caller, "
+                                        "frame_colorization(...) called positionally per frame with the same exemplar tensors, no "
+                                        "ClipColorizer in the caller, every launch from Python; the exemplar side is memoised behind "
+                                        "the call on the identity / version counters of the caller's tensors (bit-identical to "
+                                        "recomputing it; tests/test_gpu_dropin_loop.py)"),
                        "eager_launch_clip_driver_frames_per_s": None if eager_fps is None else round(eager_fps, 3),
                        "batched_clips": batched,
                        "multi_reference": None if multi is None else dict(
                            multi, speedup_vs_one_pass_per_reference=round(multi["frame_colorizations_per_s"] / (fps / n_gpus), 3))},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "parity": parity,
         }
         print(json.dumps(line), flush=True)
     if use_dist:

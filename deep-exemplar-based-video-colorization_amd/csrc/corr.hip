@@ -749,6 +749,12 @@ extern "C" int dvc_corr_fwd(const float* theta, const float* phi, const float* b
     if (y_up || sim_up)
         DVC_REQUIRE(((reinterpret_cast<uintptr_t>(y_up) | reinterpret_cast<uintptr_t>(sim_up)) & 15) == 0,
                     "dvc_corr_fwd: upsampled outputs must be 16-byte aligned");
+    // every output NULL = the merge is left to dvc_corr_merge_pack, which reads ONE image's single-pass partial states out of
+    // `workspace`: a batch would overwrite them image by image, and a WTA call leaves its second pass's states unmerged
+    if (!y_small && !sim_small && !y_up && !sim_up && !argmax)
+        DVC_REQUIRE(B == 1 && wta_scale == 1.0f,
+                    "dvc_corr_fwd: a deferred merge (every output NULL) needs B == 1 and wta_scale == 1 (got B = %d, wta_scale = %g)",
+                    B, (double)wta_scale);
     // One image per set of launches, each with the single-image decomposition: an image's result does not depend on the
     // batch it came in (the stream-K unit ranges, hence the order in which partial softmax states are merged, would
     // otherwise change with B).  The launches are 0.13 ms each; nothing is lost.

@@ -152,3 +152,11 @@ def colorvidnet_param_shapes(ic=7):
         out[f"{key}.weight"] = (c["cout"], cin, 3, 3)
         out[f"{key}.bias"] = (c["cout"],)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Error-aware engine map (ops.direct_layers): the 3x3 layers that stay on the direct implicit-GEMM engine under the default
+# algorithm choice because their Winograd rounding moves the frame's ab output the most per microsecond saved
+# (tools/engine_sensitivity.py on the MI355X, profiles/r05_engine_sensitivity.txt).  Names = state_dict prefixes with the
+# network in front ("vgg.", "warp.", "cvn.").
+DIRECT_LAYERS = frozenset()

@@ -22,6 +22,24 @@ from . import _lib, ops
 from .ops import EPS64, _p, _stream
 
 ROW_BLOCK = 2048
+BLOCK_BYTES = 256 << 20      # cap of one [B, R, Ny] fp32 buffer (S, and dS^T in the backward pass): R shrinks for big B * Ny
+
+
+def _row_block(B, Nx, Ny):
+    """Rows of S per block: ROW_BLOCK, fewer when the whole batch's block would exceed BLOCK_BYTES (B = 16 on an
+    un-downsampled relu3_1, Ny = 5184: 2048 rows would be 0.7 GB per buffer); always a multiple of 64."""
+    cap = max(64, (BLOCK_BYTES // (4 * B * Ny)) // 64 * 64)
+    return min(ROW_BLOCK, cap, (Nx + 63) // 64 * 64)
+
+
+def _apply(X, Y, h, centering, mode):
+    """The batched launch plan needs 16-byte aligned per-image filters (C * R and Ny * C multiples of 4); odd feature-map
+    sizes take one image per call, as up to r03."""
+    B, C = X.shape[0], X.shape[1]
+    Ny = Y[0, 0].numel()
+    if B > 1 and (Ny * C) % 4 != 0:
+        return torch.cat([_ContextualCX.apply(X[b:b + 1], Y[b:b + 1], h, centering, mode) for b in range(B)])
+    return _ContextualCX.apply(X, Y, h, centering, mode)
 
 
 def _ip(t):
@@ -52,7 +70,7 @@ class _ContextualCX(torch.autograd.Function):
         cmax = torch.full((B, Ny), -1.0, **f32) if mode == 1 else None
         cargi = torch.zeros((B, Ny), device=dev, dtype=torch.int32) if mode == 1 else None
         loss, gscale = torch.empty(B, **f32), torch.empty(B, **f32)
-        R = min(ROW_BLOCK, (Nx + 63) // 64 * 64)
+        R = _row_block(B, Nx, Ny)
         hy, wy = (Y.shape[2], Y.shape[3]) if Y.dim() == 4 else (1, Ny)
         # r04: the whole batch per launch — S[b] = Xn[b]^T Yn[b] is a 1x1 convolution with PER-IMAGE filters (a batched GEMM,
         # DvcConvDesc.w_batch_stride) and the row / column kernels take the batch as a grid dimension
@@ -91,7 +109,7 @@ class _ContextualCX(torch.autograd.Function):
         # the incoming per-sample gradient is folded into the per-sample scale ON THE DEVICE (dvc_cx_ds multiplies the two):
         # no host read-back, the backward pass only enqueues
         gs = (gscale * gout.detach().to(gscale.dtype)).contiguous()
-        R = min(ROW_BLOCK, (Nx + 63) // 64 * 64)
+        R = _row_block(B, Nx, Ny)
         S = torch.empty((B, R, hy, wy), **f32)
         blk = torch.zeros((B, C, 1, R), **f32)
         dST = torch.empty((B, Ny, R // 32, 32), **f32)                       # [Ny][R] per image, as an image of R "pixels"
@@ -148,7 +166,7 @@ class ContextualLoss_forward(nn.Module):
         """X_features & Y_features are feature vectors or feature 2d arrays; h: bandwidth; returns the per-sample loss
         (models/ContextualLoss.py:97-126: CX = mean over X positions of the row maxima of A)."""
         _check(X_features, Y_features)
-        return _ContextualCX.apply(X_features, Y_features, float(h), bool(feature_centering), 0)
+        return _apply(X_features, Y_features, float(h), bool(feature_centering), 0)
 
 
 class ContextualLoss(nn.Module):
@@ -162,4 +180,4 @@ class ContextualLoss(nn.Module):
     def forward(self, X_features, Y_features, h=0.1, feature_centering=True):
         """models/ContextualLoss.py:38-77: CX = mean over Y positions of the column maxima of A."""
         _check(X_features, Y_features)
-        return _ContextualCX.apply(X_features, Y_features, float(h), bool(feature_centering), 1)
+        return _apply(X_features, Y_features, float(h), bool(feature_centering), 1)

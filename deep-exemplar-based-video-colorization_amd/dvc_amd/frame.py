@@ -21,6 +21,18 @@ def warp_color(IA_l, IB_lab, features_B, vggnet, nonlocal_net, colornet, feature
     # NOTE: output the feature before normalization (FrameColor.py:13-14)
     features_A = [A_relu1_1, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1]
     nA = ops.channel_l2norm_multi(features_A[1:])            # feature_normalize x4 (FrameColor.py:16-19), one launch
+    if exemplar_cache is None and ops.exemplar_memo_enabled() and hasattr(nonlocal_net, "_memo_exemplar_side"):
+        # the reference's own call pattern (test.py:85-95: the same `IB_lab` / `features_B` objects every frame): the exemplar
+        # side (FrameColor.py:20-23 + NonlocalNet.py:452-465,473-476,491-493) is computed on the first call and reused while
+        # those tensors, the WarpNet parameters and the kernel selection are unchanged — bit-identical to recomputing it
+        bf16 = nonlocal_net._use_bf16(temperature, 1)
+
+        def exemplar_side():
+            nB = ops.channel_l2norm_multi((B_relu2_1, B_relu3_1, B_relu4_1, B_relu5_1))
+            return nonlocal_net.exemplar_side(IB_lab.detach().contiguous().float(), *nB, bf16=bf16)
+
+        exemplar_cache = nonlocal_net._memo_exemplar_side((IB_lab, B_relu2_1, B_relu3_1, B_relu4_1, B_relu5_1),
+                                                          ("warp_color", bf16), exemplar_side)
     if exemplar_cache is None:
         nB = ops.channel_l2norm_multi((B_relu2_1, B_relu3_1, B_relu4_1, B_relu5_1))
         kw = dict(defer_merge=True) if defer_merge else {}
@@ -152,6 +164,15 @@ class ClipColorizer:
         fp = [(p.data_ptr(), p._version) for p in params[0]]
         if fp != self._weights_fp:
             self.prepare()
+            # the cached exemplar side (phi, pooled Lab) was computed with the VGG19 / WarpNet weights of its time: when THOSE
+            # moved, it is recomputed from the exemplar (into the same buffers when captured front ends read them) — a new A
+            # side must never meet a stale B side
+            n_front = sum(1 for net in (self.vgg, self.warp) for _ in net.parameters())
+            if (self._weights_fp is not None and fp[:n_front] != self._weights_fp[:n_front] and self.ex_cache is not None
+                    and self.IB_lab is not None and self.features_B is not None):
+                n = self.n_refs
+                self.set_exemplar(self.IB_lab)
+                self.n_refs = n
             self._weights_fp = fp
 
     def set_exemplar(self, IB_lab):
@@ -292,6 +313,7 @@ class ClipColorizer:
         """One frame_colorization call (the per-frame API of test.py:85): returns (ab, warped Lab).
         In multi-reference mode (set_exemplars) `IA_lab` is the one frame, `IA_last_lab` the R previous [L, ab] tensors
         [R,3,H,W]; returns (ab [R,2,H,W], warped Lab [R,3,H,W]); launches are issued from Python (`graph` is not used)."""
+        self._sync_weights()
         if self.n_refs > 1:     # one frame against the R references: IA_last_lab [R,3,H,W] -> (ab [R,2,H,W], warped [R,3,H,W])
             IA_lab = IA_lab.detach().contiguous().float()
             warped, sim, _ = warp_color(IA_lab[:, 0:1], self.IB_lab, None, self.vgg, self.warp, self.col, 0,
@@ -299,7 +321,7 @@ class ClipColorizer:
             cin, warped = ops.pack_color_input(self._rep(IA_lab), warped, sim, IA_last_lab.detach().contiguous().float(),
                                                want_warped=True)
             return self._chain(cin), warped
-        if self.graph if graph is None else graph:
+        if (self.graph if graph is None else graph) and not self.batch_plan:      # (batch-planned launches: eager, as in clip())
             return self._frame_graph(IA_lab.detach().contiguous().float(),
                                      dict(IA_last_lab=IA_last_lab.detach().contiguous().float()))
         ab, nl, _ = frame_colorization(IA_lab, self.IB_lab, IA_last_lab, self.features_B, self.vgg, self.warp,
@@ -344,6 +366,7 @@ class ClipColorizer:
         frames_lab = [f.detach().contiguous().float() for f in frames_lab]
         if not frames_lab:
             return []
+        self._sync_weights()
         use_graph = (self.graph if graph is None else bool(graph)) and not self.batch_plan      # (batch-planned launches: eager)
         multi = self.n_refs > 1
         if multi:

@@ -155,10 +155,14 @@ class VGG19_pytorch(nn.Module):
                     cur = ops.maxpool2x2(cur) if self._pool == "max" else ops.avgpool2x2(cur)
             elif (self._pool == "max" and ops.pool_fusion() and i + 1 <= last and arch.VGG_KEYS[i + 1][0] == "p"
                   and min(cur.shape[2:]) >= 2
-                  and ops.winograd_selected(N, cur.shape[1], cur.shape[2], cur.shape[3], getattr(self, conv_names[key]).weight.shape[0])):
+                  and ops.winograd_selected(N, cur.shape[1], cur.shape[2], cur.shape[3], getattr(self, conv_names[key]).weight.shape[0],
+                                            layer="vgg." + conv_names[key])):
                 # relu1_2 / relu2_2 / relu3_4 / relu4_4 -> pool: the pooled tensor comes out of the convolution's own launch; the
                 # full-resolution one only when somebody asked for it
                 conv = getattr(self, conv_names[key])
+                if ops.layer_record is not None:
+                    ops.layer_record.append(dict(layer="vgg." + conv_names[key], Cin=cur.shape[1], Cout=conv.weight.shape[0],
+                                                 H=cur.shape[2], W=cur.shape[3], dil=1, in_up=1, in_sub=1, eligible=True))
                 cur, pooled = ops.conv2d_winograd_pool(cur, _packs(self._cache, conv_names[key], conv.weight)("winograd"),
                                                        conv.bias.detach(), act=ops.ACT_RELU, want_full=key in out_keys)
             else:
@@ -171,7 +175,8 @@ class VGG19_pytorch(nn.Module):
                     cur = ops.conv2d(cur, self._packed(name, swap_bgr=True), bias, act=ops.ACT_RELU,
                                      in_scale=sc, in_shift=sh)
                 else:
-                    cur = ops.conv3x3(cur, conv.weight, _packs(self._cache, name, conv.weight), bias, act=ops.ACT_RELU)
+                    cur = ops.conv3x3(cur, conv.weight, _packs(self._cache, name, conv.weight), bias, act=ops.ACT_RELU,
+                                      layer="vgg." + name)
             out[key] = cur
         return [out[key] for key in out_keys]
 
@@ -225,7 +230,7 @@ class WarpNet(nn.Module):
         return self._cache.get(key, conv.weight, ops.pack_conv_weight)
 
     def _conv3(self, key, conv, x, **kw):
-        return ops.conv3x3(x, conv.weight, _packs(self._cache, key, conv.weight), conv.bias.detach(), **kw)
+        return ops.conv3x3(x, conv.weight, _packs(self._cache, key, conv.weight), conv.bias.detach(), layer="warp." + key, **kw)
 
     def prepare(self):
         """Pack every weight now, on the current stream (see _PackCache.get)."""
@@ -305,6 +310,27 @@ class WarpNet(nn.Module):
         t = ops.conv2d(feats, self._pk(which, conv), conv.bias.detach(), ksize=1, pad=0)
         return ops.corr_prepare_bf16(t) if bf16 else ops.corr_prepare(t)
 
+    # ---- transparent exemplar memo (r05).  The reference's loop (test.py:68-96) hands the SAME exemplar tensors to every
+    # frame_colorization call and NonlocalNet.py:452-465,473-476,491-493 recompute the exemplar side each time.  A caller that is
+    # not rewritten around ClipColorizer gets the cached form anyway: the exemplar side is memoised on the identity and the
+    # version counters of the tensors it was computed from (the memo holds references to them, so their addresses cannot be
+    # recycled for other data while it is alive), this module's parameters (data_ptr, _version) and everything that selects
+    # kernels.  An in-place write to a key tensor bumps its `_version` and misses; writes through `.data` are invisible to
+    # version counters here as they are to autograd.  DVC_EXEMPLAR_MEMO=0 / ops.set_exemplar_memo(False) turns it off.
+    def _memo_exemplar_side(self, key_tensors, regime, compute):
+        if not ops.exemplar_memo_enabled():
+            return compute()
+        fp = (tuple((p.data_ptr(), p._version) for p in self.parameters()), regime, ops.conv_algo(), ops.direct_layers(),
+              ops.fuse_reduce(), ops.autotune_enabled(), ops.batch_plan_enabled())
+        memo = getattr(self, "_exemplar_memo", None)
+        if (memo is not None and memo[1] == fp and len(memo[0]) == len(key_tensors)
+                and all(a is b and a._version == v for (a, v), b in zip(memo[0], key_tensors))):
+            return memo[2]
+        value = compute()
+        # (object.__setattr__: the memo holds tensors, nn.Module.__setattr__ would try to register them)
+        object.__setattr__(self, "_exemplar_memo", ([(t, t._version) for t in key_tensors], fp, value))
+        return value
+
     def exemplar_side(self, B_lab_map, B2, B3, B4, B5, bf16=None):
         """Everything that depends only on the exemplar (recomputed per frame by the reference,
         NonlocalNet.py:452-465,473-476,491-493; cacheable per clip)."""
@@ -324,6 +350,7 @@ class WarpNet(nn.Module):
                B_relu5_1]
         for t in ins:
             _check_input(t, "WarpNet")
+        memo_key = (B_lab_map, B_relu2_1, B_relu3_1, B_relu4_1, B_relu5_1)      # (the caller's own tensor objects)
         ins = [t.detach().contiguous().float() for t in ins]
         B_lab_map, A2, A3, A4, A5, B2, B3, B4, B5 = ins
         image_height, image_width = B_lab_map.shape[2], B_lab_map.shape[3]
@@ -338,7 +365,8 @@ class WarpNet(nn.Module):
             if isinstance(phi, tuple) != bf16:
                 raise RuntimeError("exemplar cache was built for a different corr_precision / temperature regime")
         else:
-            phi, blab = self.exemplar_side(B_lab_map, B2, B3, B4, B5, bf16=bf16)
+            phi, blab = self._memo_exemplar_side(memo_key, ("forward", bf16),
+                                                 lambda: self.exemplar_side(B_lab_map, B2, B3, B4, B5, bf16=bf16))
         theta = self.project("theta", A_features, bf16=bf16)
         if bf16:
             res = ops.corr_fwd_bf16(theta, phi, blab.view(blab.shape[0], 3, -1), float(temperature), fh, fw,
@@ -444,8 +472,8 @@ class ColorVidNet(nn.Module):
         # (dvc_conv2d_winograd_dual forces the 64-channel x 32-tile workgroup shape and stages 8-channel chunks of each input)
         if cA["cout"] % 64 or cB["cout"] != cA["cout"] or CA % 8 or CB % 8:
             return False
-        return (ops.winograd_selected(N, CA, HA, WA, cA["cout"], dil=cA["dil"], pad=cA["dil"], in_up=upA)
-                and ops.winograd_selected(N, CB, HB, WB, cB["cout"], dil=cB["dil"], pad=cB["dil"]))
+        return (ops.winograd_selected(N, CA, HA, WA, cA["cout"], dil=cA["dil"], pad=cA["dil"], in_up=upA, layer="cvn." + cA["key"])
+                and ops.winograd_selected(N, CB, HB, WB, cB["cout"], dil=cB["dil"], pad=cB["dil"], layer="cvn." + cB["key"]))
 
     def prepare(self):
         """Pack every weight now, on the current stream (see _PackCache.get)."""
@@ -510,6 +538,11 @@ class ColorVidNet(nn.Module):
                 srcB = norm_of(e["src"]) if e["pre"] == "norm" else acts[e["src"]]
                 if self._dual_ok(c, e, srcA.shape, srcB.shape):
                     u, b = self._dual_pack(c, e)
+                    if ops.layer_record is not None:
+                        for cc_, src_ in ((c, srcA), (e, srcB)):
+                            ops.layer_record.append(dict(layer="cvn." + cc_["key"], Cin=src_.shape[1], Cout=cc_["cout"], H=src_.shape[2],
+                                                         W=src_.shape[3], dil=cc_["dil"], in_up=2 if cc_["pre"] == "up" else 1, in_sub=1,
+                                                         eligible=True, dual=c["key"]))
                     acts[c["dst"]] = ops.conv2d_winograd_dual(srcA, srcB, u, b, dil=c["dil"], in_upA=2 if c["pre"] == "up" else 1,
                                                               act=act_map[c["act"]], act_slope=0.2)
                     if c["dst"] in norm_uses:
@@ -519,7 +552,7 @@ class ColorVidNet(nn.Module):
                 # not both Winograd layers (direct algorithm, tiny maps): the skip convolution as its own launch, then the adder
                 convE = self._mod(e["key"])
                 acts[e["dst"]] = ops.conv3x3(srcB, convE.weight, _packs(self._cache, e["key"], convE.weight), convE.bias.detach(),
-                                             dil=e["dil"], act=act_map[e["act"]], act_slope=0.2)
+                                             dil=e["dil"], act=act_map[e["act"]], act_slope=0.2, layer="cvn." + e["key"])
             conv = self._mod(c["key"])
             kw = dict(dil=c["dil"], act=act_map[c["act"]], act_slope=0.2)
             pre = c["pre"]
@@ -535,7 +568,7 @@ class ColorVidNet(nn.Module):
                 kw["residual"] = acts[c["add"]]
             dst = c["dst"]
             acts[dst] = ops.conv3x3(src, conv.weight, _packs(self._cache, c["key"], conv.weight), conv.bias.detach(),
-                                    defer_reduce=dst in norm_uses and dst not in raw_use, **kw)
+                                    defer_reduce=dst in norm_uses and dst not in raw_use, layer="cvn." + c["key"], **kw)
             if dst in norm_uses:
                 if dst in both:
                     norm_of(dst)

@@ -60,6 +60,7 @@ def _need(t, name):
 
 
 conv_record = None   # set to a list to log every conv2d launch (tools/tune_conv.py)
+layer_record = None  # set to a list to log every NAMED 3x3 layer that goes through conv3x3 (tools/engine_sensitivity.py)
 
 # ---- autotuning (the analogue of the reference's `cudnn.benchmark = True`, test.py:140): the first
 # time a conv geometry is seen, every (tile configuration, split-K) candidate is timed once on the
@@ -406,8 +407,8 @@ def set_fuse_reduce(flag=True):
 
 def set_conv_algo(algo):
     global _conv_algo
-    if algo not in ("auto", "direct", "winograd"):
-        raise ValueError("conv algo must be 'auto', 'direct' or 'winograd'")
+    if algo not in ("auto", "speed", "direct", "winograd"):
+        raise ValueError("conv algo must be 'auto', 'speed', 'direct' or 'winograd'")
     _conv_algo = algo
 
 
@@ -415,13 +416,57 @@ def conv_algo():
     return _conv_algo
 
 
+# the exemplar side of WarpNet memoised behind the reference's unmodified call pattern (nets.WarpNet._memo_exemplar_side)
+_exemplar_memo = _os.environ.get("DVC_EXEMPLAR_MEMO", "1") != "0"
+
+
+def exemplar_memo_enabled():
+    return _exemplar_memo
+
+
+def set_exemplar_memo(flag=True):
+    global _exemplar_memo
+    _exemplar_memo = bool(flag)
+
+
+# ---- error-aware engine map (r05).  Winograd F(2x2,3x3) rounds 2-3x coarser than the direct sum per layer, and through the
+# 31 layers of a frame the timed engine ended up FURTHER from the fp64 truth than the reference's own CPU fp32 (r04 review:
+# 216x384, plain seed-0 weights, q999 1.8x / max 2.8x the CPU run's).  `tools/engine_sensitivity.py` measures, per named layer,
+# what switching that ONE layer from the direct engine to Winograd does to the frame's ab output (the perturbation field, no
+# truth needed) and ranks the layers by perturbation energy per microsecond saved; the layers below are the ones "auto" keeps
+# on the direct engine so that the whole path is at or below the CPU fp32 run's error against fp64
+# (profiles/r05_engine_sensitivity.txt; asserted by tests/test_gpu_nets.py::test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32).
+# Names: "vgg.<conv>", "warp.<head>.<index>" / "warp.layer.<b>.conv<k>", "cvn.<key>" (the reference's state_dict prefixes).
+# "speed" is the geometry-only rule (what "auto" meant up to r04), "winograd" / "direct" force one engine.
+DEFAULT_DIRECT_LAYERS = frozenset(_os.environ["DVC_DIRECT_LAYERS"].split(",")) if _os.environ.get("DVC_DIRECT_LAYERS") is not None else None
+_direct_layers = None      # None: the built-in map (arch.DIRECT_LAYERS); a frozenset: an explicit one
+
+
+def direct_layers():
+    """Names of the layers `auto` keeps on the direct engine."""
+    if _direct_layers is not None:
+        return _direct_layers
+    if DEFAULT_DIRECT_LAYERS is not None:
+        return DEFAULT_DIRECT_LAYERS
+    from . import arch
+    return arch.DIRECT_LAYERS
+
+
+def set_direct_layers(names=None):
+    """Replace the error-aware map (None: back to the built-in one).  Captured launch sequences notice (graph._epoch)."""
+    global _direct_layers
+    _direct_layers = None if names is None else frozenset(names)
+
+
 def winograd_selected(N, Cin, H, W, Cout, *, ksize=3, stride=1, dil=1, pad=1, in_up=1, in_sub=1, in_affine=False,
-                      in_prelu=False):
+                      in_prelu=False, layer=None):
     """True if the current algorithm choice sends this layer to dvc_conv2d_winograd."""
     if _conv_algo == "direct" or not winograd_eligible(Cin, Cout, ksize, stride, dil, pad, in_affine, in_prelu):
         return False
     if _conv_algo == "winograd":
         return True
+    if _conv_algo == "auto" and layer is not None and layer in direct_layers():
+        return False
     OH, OW = conv_out_hw(H, W, ksize, stride, dil, pad, in_up, in_sub)
     return _wino_rule(N, Cin, Cout, OH, OW, dil)
 
@@ -439,12 +484,17 @@ def _wino_rule(N, Cin, Cout, OH, OW, dil):
 
 
 def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1, act=ACT_NONE, act_slope=0.0,
-            act_slope_t=None, residual=None, out=None, out_batch_stride=0, defer_reduce=False):
+            act_slope_t=None, residual=None, out=None, out_batch_stride=0, defer_reduce=False, layer=None):
     """A 3x3 stride-1 pad == dil layer through whichever engine the algorithm choice selects.  `packs(kind)` returns
-    the packed weight for kind "direct" ([Cin][9][Cout]) or "winograd" (U = G g G^T), normally from a _PackCache."""
+    the packed weight for kind "direct" ([Cin][9][Cout]) or "winograd" (U = G g G^T), normally from a _PackCache.
+    `layer`: the layer's name in the error-aware engine map (direct_layers)."""
     N, Cin, H, W = x.shape
     Cout = weight.shape[0]
-    if winograd_selected(N, Cin, H, W, Cout, dil=dil, pad=dil, in_up=in_up, in_sub=in_sub):
+    if layer_record is not None:
+        layer_record.append(dict(layer=layer, Cin=Cin, Cout=Cout, H=H, W=W, dil=dil, in_up=in_up, in_sub=in_sub,
+                                 eligible=winograd_eligible(Cin, Cout, 3, 1, dil, dil)
+                                 and _wino_rule(N, Cin, Cout, *conv_out_hw(H, W, 3, 1, dil, dil, in_up, in_sub), dil)))
+    if winograd_selected(N, Cin, H, W, Cout, dil=dil, pad=dil, in_up=in_up, in_sub=in_sub, layer=layer):
         return conv2d_winograd(x, packs("winograd"), bias, dil=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub,
                                act=act, act_slope=act_slope, act_slope_t=act_slope_t, residual=residual, out=out,
                                out_batch_stride=out_batch_stride, defer_reduce=defer_reduce and _fuse_reduce)
@@ -882,6 +932,10 @@ def corr_fwd(theta, phi, blab, temperature, h, w, wta_scale=1.0, want_small=Fals
                                         ctypes.c_void_p(bufs[b].data_ptr()), bufs[b].numel(), st), "dvc_corr_fwd")
         return CorrPartials(bufs, h, w, temperature)
     out = {}
+    if not (want_up or want_small or want_argmax):
+        # (at the C-ABI "every output NULL" means a deferred merge: never reach it by accident)
+        raise ValueError("dvc_amd: corr_fwd: no output requested (want_up / want_small / want_argmax all False); pass "
+                         "defer_merge=True to leave the merge to pack_color_input")
     y_up = sim_up = y_small = sim_small = amax = None
     if want_up:
         y_up = torch.empty((B, 3, 4 * h, 4 * w), device=dev, dtype=torch.float32)

@@ -9,7 +9,7 @@ TEST INFRASTRUCTURE ONLY (imported by tests/ and tools/, never by the product pa
 
 Pinning status:
   * `upsample_ab` is pinned: the reference calls torch.nn.functional.interpolate itself, and
-    tests/test_tail_oracle.py checks this restatement against it bit for bit.
+    tests/test_tail.py checks this restatement against it bit for bit.
   * `luminance_guide_u8` is plain arithmetic (float32 multiply / divide / truncation), as numpy does it.
   * `fgs_filter` and `lab_to_rgb8` are **parity unpinned**: cv2.ximgproc (opencv-contrib) and skimage are
     third-party dependencies that are neither vendored in /root/reference nor installed in this image

@@ -243,3 +243,106 @@ def test_batch_plan_flag_trades_the_split_for_the_batch():
         with ops.batch_plan(False):
             assert ops._plan_flags(4) == 0
     assert not ops.batch_plan_enabled()
+
+
+def test_bench_torchrun_relaunch_command():
+    """`python bench.py --gpus N` re-launches itself as the driver does (one rank per GPU under torch.distributed.run, 127.0.0.1
+    rendezvous, its own flags passed through): the command line is built here without launching anything."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd, env = bench.torchrun_command(8, argv, 29511, environ={"PATH": "/usr/bin"})
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == argv                       # the ranks get exactly the caller's flags (--gpus N included)
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/usr/bin"
+    _, env1 = bench.torchrun_command(2, [], 1, environ={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+    assert env1["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"      # an explicit setting of the caller is kept
+
+
+def test_error_aware_engine_map_host_logic():
+    """ops.winograd_selected with named layers: under `auto` the layers of the engine map stay on the direct engine, `speed` is
+    the geometry rule alone, `winograd` / `direct` force one engine; the map never depends on the batch size; every name in the
+    built-in map is a real 3x3 layer of one of the three networks."""
+    from dvc_amd import arch, ops
+    old_algo, old_map = ops.conv_algo(), ops._direct_layers
+    try:
+        geo = dict(dil=1, pad=1)
+        ops.set_conv_algo("auto")
+        ops.set_direct_layers(["cvn.conv2_2"])
+        assert not ops.winograd_selected(1, 128, 108, 192, 128, layer="cvn.conv2_2", **geo)
+        assert not ops.winograd_selected(4, 128, 108, 192, 128, layer="cvn.conv2_2", **geo)
+        assert ops.winograd_selected(1, 128, 108, 192, 128, layer="cvn.conv9_2", **geo)
+        assert ops.winograd_selected(1, 128, 108, 192, 128, **geo)                  # unnamed calls: geometry rule
+        ops.set_conv_algo("speed")
+        assert ops.winograd_selected(1, 128, 108, 192, 128, layer="cvn.conv2_2", **geo)
+        ops.set_conv_algo("winograd")
+        assert ops.winograd_selected(1, 128, 108, 192, 128, layer="cvn.conv2_2", **geo)
+        ops.set_conv_algo("direct")
+        assert not ops.winograd_selected(1, 128, 108, 192, 128, layer="cvn.conv9_2", **geo)
+        ops.set_direct_layers(None)
+        assert ops.direct_layers() == arch.DIRECT_LAYERS
+        with pytest.raises(ValueError):
+            ops.set_conv_algo("fastest")
+    finally:
+        ops.set_conv_algo(old_algo)
+        ops._direct_layers = old_map
+    names = {"vgg." + n for n, _, _ in arch.VGG_CONVS}
+    names |= {f"warp.{h}.{ci}" for h in arch.WARP_HEAD_ORDER for (ci, _, _, _, _) in arch.WARP_HEADS[h]["convs"]}
+    names |= {f"warp.layer.{b}.conv{k}" for b in range(arch.WARP_NUM_RESBLOCKS) for k in (1, 2)}
+    names |= {"cvn." + c["key"] for c in arch.CVN_CONVS}
+    assert arch.DIRECT_LAYERS <= names, sorted(arch.DIRECT_LAYERS - names)
+
+
+def test_exemplar_memo_keys_on_identity_versions_and_weights():
+    """nets.WarpNet._memo_exemplar_side (the cache behind the reference's unmodified call pattern), on CPU tensors with a
+    counting stand-in for the exemplar side: hit on the same tensor objects, miss on new objects, on an in-place write
+    (version counter), on a parameter update, on another regime / engine choice; off switch."""
+    import contextlib
+    import io
+    from dvc_amd import ops
+    from dvc_amd.nets import WarpNet
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = WarpNet(1)
+    calls = []
+
+    def compute():
+        calls.append(1)
+        return ("phi%d" % len(calls), "blab")
+
+    a, b = torch.zeros(3), torch.zeros(4)
+    v1 = net._memo_exemplar_side((a, b), ("warp_color", False), compute)
+    assert net._memo_exemplar_side((a, b), ("warp_color", False), compute) is v1 and len(calls) == 1
+    assert net._memo_exemplar_side((a.clone(), b), ("warp_color", False), compute) is not v1 and len(calls) == 2     # new object
+    net._memo_exemplar_side((a, b), ("warp_color", False), compute)
+    n = len(calls)
+    a.add_(1.0)                                                                                                      # in-place write
+    net._memo_exemplar_side((a, b), ("warp_color", False), compute)
+    assert len(calls) == n + 1
+    net._memo_exemplar_side((a, b), ("warp_color", True), compute)                                                   # other regime
+    assert len(calls) == n + 2
+    with torch.no_grad():
+        net.theta.weight.mul_(2.0)                                                                                    # parameter update
+    net._memo_exemplar_side((a, b), ("warp_color", True), compute)
+    assert len(calls) == n + 3
+    old = ops.conv_algo()
+    try:
+        ops.set_conv_algo("direct")
+        net._memo_exemplar_side((a, b), ("warp_color", True), compute)
+        assert len(calls) == n + 4
+    finally:
+        ops.set_conv_algo(old)
+    ops.set_exemplar_memo(False)
+    try:
+        net._memo_exemplar_side((a, b), ("warp_color", True), compute)
+        net._memo_exemplar_side((a, b), ("warp_color", True), compute)
+        assert len(calls) == n + 6
+    finally:
+        ops.set_exemplar_memo(True)
+    # the memo is not part of the module's state
+    assert not any("memo" in k for k in net.state_dict())

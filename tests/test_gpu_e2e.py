@@ -328,3 +328,36 @@ def test_near_tie_frames_216x384_bounded_behaviour(seed):
     assert d_alt.max().item() <= NORTH_STAR_TOL, d_alt.max().item()      # (iii)
     if not flipped.any():
         assert d_plain.max().item() <= NORTH_STAR_TOL
+
+
+@pytest.mark.parametrize("B", [1, 2])
+@pytest.mark.parametrize("T", [0.01, 0.005])
+@pytest.mark.parametrize("H,W", [(40, 64), (216, 384)])
+def test_soft_temperature_free_running_clip_within_1e3(H, W, T, B):
+    """The API's other regime, end to end (r04 review, item 4): `frame_colorization`'s default temperature 0.01
+    (FrameColor.py:52) and WarpNet.forward's 0.005 (NonlocalNet.py:438), 4 free-running frames, at 40x64 — where layer5_1's
+    output is one row short and NonlocalNet.py:461-463 pads a replicated row top and bottom — and at 216x384, for one clip
+    and for a batch of two independent clips (each with its own exemplar; train.py:402 calls the function with B = 16):
+    |ab_gpu - ab_oracle| <= 1e-3 on every frame of every clip.  At these temperatures every key contributes to every query's
+    colour (no arg-max to flip), so any frame seed serves."""
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    from oracle import dvc_oracle as O
+    _oracle_threads()
+    sd = _state_dicts()
+    NF = 4
+    IBs = [synth.synth_lab(synth.EXEMPLAR_SEED + b, H, W) for b in range(B)]
+    clips = [[synth.synth_lab(synth.FRAME_SEED0 + 100 * b + i, H, W) for i in range(NF)] for b in range(B)]
+    cc = ClipColorizer(*_fresh_nets(sd), temperature=T)
+    cc.set_exemplar(torch.cat(IBs).cuda())
+    got = cc.clip([torch.cat([clips[b][i] for b in range(B)]).cuda() for i in range(NF)], lookahead=2)
+    torch.cuda.synchronize()
+    for b in range(B):
+        with torch.no_grad():
+            ref = O.colorize_clip(clips[b], IBs[b], *sd, temperature=T)
+        for i in range(NF):
+            d = (got[i][b:b + 1].cpu() - ref[i]).abs()
+            report(f"e2e soft temperature {H}x{W} T={T} B={B} clip{b} frame{i}: |ab| max={ref[i].abs().max():.2f} "
+                   f"gpu-vs-oracle max={d.max():.2e} mean={d.mean():.2e}")
+            assert ref[i].abs().max().item() > 1.0
+            assert d.max().item() <= NORTH_STAR_TOL, (b, i, d.max().item())

@@ -346,9 +346,22 @@ def test_frame_colorization_vs_reference_golden(nets, weights, golden_dir, name,
             assert d.mean() < 2e-3 and np.quantile(d, 0.99) < 1e-2, (name, i)
             assert d.max() < WORST_CASE_FACTOR[conv_algo] * 1e-2, (name, i, d.max())
         else:   # soft temperature: d(y)/d(f) = |B_lab|/T ~ 1e4 and fp32 affinities differ by ~1e-6
+            # The bound is the reference's OWN fp32 noise at this temperature, measured here: the golden (= the reference's fp32
+            # run) against the fp64 truth on the same inputs.  A GPU result no further from the truth than the golden is lies
+            # within 2x that figure of the golden (triangle inequality); the maximum of the error field gets 2.5x.
             d = np.abs(ab[0].cpu().numpy() - g["ab"][i])
-            report(f"e2e golden {name} conv={conv_algo} frame{i}: ab max={d.max():.2e} mean={d.mean():.2e} warped max={wl.max():.2e}")
-            assert wl.max() < 5e-2 and d.mean() < 0.1, (name, i)
+            sd64 = tuple(O.to_dtype(s_, torch.float64) for s_ in weights)
+            with torch.no_grad():
+                fB64 = O.exemplar_features(IB.cpu().double(), sd64[0])
+                ab64, nl64, _ = O.frame_colorization(fr.cpu().double(), IB.cpu().double(), last.cpu().double(), fB64, *sd64, temperature=T)
+            e_ref = np.abs(g["ab"][i] - ab64[0].numpy())
+            w_ref = np.abs(g["warped_lab_small"][i] - nl64[0, :, ::4, ::4].numpy())
+            report(f"e2e golden {name} conv={conv_algo} frame{i}: ab max={d.max():.2e} mean={d.mean():.2e} warped max={wl.max():.2e} | "
+                   f"golden (reference fp32) vs fp64 on the same inputs: ab max={e_ref.max():.2e} mean={e_ref.mean():.2e} "
+                   f"warped max={w_ref.max():.2e}")
+            assert d.mean() <= 2.0 * e_ref.mean(), (name, i, d.mean(), e_ref.mean())
+            assert d.max() <= 2.5 * e_ref.max(), (name, i, d.max(), e_ref.max())
+            assert wl.max() <= 2.0 * w_ref.max() + 1e-4, (name, i, wl.max(), w_ref.max())
 
 
 @pytest.mark.parametrize("H,W,T", [(48, 80, 1e-10), (40, 64, 0.01), (216, 384, 1e-10)])
