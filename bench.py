@@ -59,6 +59,12 @@ def corr_traffic():
     try:
         raw = open(path, "rb").read()
         rec = json.loads(raw)
+        src = hashlib.sha256(open(os.path.join(PKG, "csrc", "corr.hip"), "rb").read()).hexdigest()[:16]
+        if rec.get("corr_hip_sha256_16") != src:
+            # the PMC passes ran another version of the kernel's source: a constant that silently goes stale is worse than none
+            return None, {"kind": "stale: csrc/corr.hip (sha256 %s) is not the source the PMC passes measured (%s); re-run "
+                                  "tools/gpu_final.sh + tools/summarize_profiles.py" % (src, rec.get("corr_hip_sha256_16")),
+                          "file": CORR_TRAFFIC_FILE}
         return float(rec["bytes_per_launch"]), {"kind": "offline rocprofv3 --pmc passes, not re-measured by this run",
                                                 "file": CORR_TRAFFIC_FILE, "sha256_16": hashlib.sha256(raw).hexdigest()[:16],
                                                 "measured_on": rec.get("measured_on"), "P": rec.get("P")}
@@ -218,9 +224,20 @@ def parity_block(cc, sd, device):
         ab, _ = cc.frame(fr.to(device), z.to(device), graph=False)
         st = lambda e: {"max": float(e.max()), "q999": float(np.quantile(e.numpy(), 0.999)), "mean": float(e.mean())}   # noqa: E731
         g, c = st((ab.double().cpu() - ab64).abs()), st((ab32.double() - ab64).abs())
+        speed = None
+        if ops.conv_algo() == "auto":
+            # what the geometry-only Winograd rule (r01-r04's engine choice, `config.engine_speed`) would have cost here
+            try:
+                ops.set_conv_algo("speed")
+                ab_s, _ = cc.frame(fr.to(device), z.to(device), graph=False)
+                gs = st((ab_s.double().cpu() - ab64).abs())
+                speed = {"gpu_vs_fp64": {k: float("%.4g" % v) for k, v in gs.items()}, "gpu_over_cpu32": {k: round(gs[k] / c[k], 3) for k in gs}}
+            finally:
+                ops.set_conv_algo("auto")
         return {"gpu_vs_fp64": {k: float("%.4g" % v) for k, v in g.items()}, "cpu32_vs_fp64": {k: float("%.4g" % v) for k, v in c.items()},
                 "gpu_over_cpu32": {k: round(g[k] / c[k], 3) for k in g}, "conv_algo": ops.conv_algo(),
                 "direct_layers": sorted(ops.direct_layers()) if ops.conv_algo() == "auto" else None,
+                "engine_speed_for_comparison": speed,
                 "sample": "ab of one 216x384 frame (first frame of a clip, exemplar seed 2, frame seed 1000, plain seed-0 weights, "
                           "T = 1e-10): |GPU fp32 - oracle fp64| and |oracle fp32 (= the reference's CPU run) - oracle fp64| over the "
                           f"2 x 216 x 384 values; untimed, oracle on the host CPU ({t_cpu:.0f} s)"}
@@ -280,6 +297,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-speed-leg", action="store_true", help="skip the config.engine_speed leg (the K frames under DVC_CONV_ALGO=speed)")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity block (GPU and CPU fp32 against the fp64 oracle)")
     ap.add_argument("--clock-warmup-s", type=float, default=0.5,
                     help="seconds of untimed load (the warm-up frames, repeated) before the W warm-up steps, so that the "
@@ -567,6 +585,7 @@ def main():
                            "frame_colorization, train.py:402 calls it with B = 16): front ends and ColorVidNet chain at batch B with the "
                            "batch-aware launch plan; per-clip results equal the single-clip driver's to fp32 rounding of the summation "
                            "order (tests/test_gpu_refs.py)"}
+    last_before = last          # recurrence state the timed clip started from
     last = last_timed
     t = torch.tensor(rep_s, device=device, dtype=torch.float64)
     if use_dist:
@@ -677,6 +696,28 @@ def main():
 
     if rank == 0 and roof is not None and bf16_roof is not None:
         roof = dict(bf16_roof, hbm_view=roof["hbm_view"], whole_path=roof["whole_path"])
+    # ---- the same K frames under the geometry-only Winograd rule ("speed": what r01-r04 timed as the default): reported next to
+    # `value`, never as `value` — at this configuration that engine is further from the fp64 truth than the reference's own CPU
+    # fp32 run (parity.engine_speed_for_comparison), which is why the default keeps arch.DIRECT_LAYERS on the direct engine
+    speed_leg = None
+    if rank == 0 and args.lookahead > 0 and ops.conv_algo() == "auto" and ops.direct_layers() and not args.no_speed_leg:
+        try:
+            ops.set_conv_algo("speed")
+            cc.clip(frames[:max(Wm, 3)], lookahead=args.lookahead, graph=clip_graph)      # re-capture / autotune under this engine
+            cc.clip(frames[:max(Wm, 3)], lookahead=args.lookahead, graph=clip_graph)
+
+            def speed_clip():
+                cc.clip(frames[Wm:Wm + K], last=last_before, lookahead=args.lookahead, graph=clip_graph)
+                return cc.last_lab
+            t_sp, last_sp = median_s(speed_clip, side_reps)
+            assert torch.isfinite(last_sp).all()
+            speed_leg = {"frames_per_s": round(K / t_sp, 3), "ms_per_step": round(t_sp / K * 1e3, 4),
+                         "note": "Winograd F(2x2,3x3) on every eligible layer (geometry rule only, DVC_CONV_ALGO=speed): the engine "
+                                 "choice of r01-r04, timed here with the same driver on the same frames; NOT the headline — see "
+                                 "parity.engine_speed_for_comparison for what it costs in accuracy"}
+        finally:
+            ops.set_conv_algo("auto")
+            cc.clip(frames[:max(Wm, 3)], lookahead=args.lookahead, graph=clip_graph)      # back to the default engine's sequences
     cpu = parity = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd)
@@ -722,6 +763,7 @@ def main():
                                     "chain launched kernel by kernel; per-frame API: both sequences replayed; bit-identical to "
                                     "eager launches (fixed mode, no warm-up trial)") if use_graph else
                                    (graph_note or "every kernel launched from Python"),
+                       "engine_speed": speed_leg,
                        "per_frame_api_frames_per_s": None if seq_fps is None else round(seq_fps, 3),
                        "dropin_unmodified_frames_per_s": None if dropin is None else dropin["frames_per_s"],
                        "dropin_unmodified": None if dropin is None else dict(

@@ -102,26 +102,42 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 //   m_l = b_l - a_l c'_{l-1},  inv_l = 1 / m_l,  c'_l = c_l inv_l            (one divide per element, here)
 //   d'_l = (f_l - a_l d'_{l-1}) inv_l = fma(-(a_l inv_l), d'_{l-1}, f_l inv_l) (one dependent fma per element, below)
 // Both kernels: one thread per line, FGS_U elements fetched ahead of the dependent chain.
+// r05: the loads of block k+1 are issued BEFORE the dependent chain of block k runs (two register sets, the block loop unrolled
+// twice).  With one thread per line there are only planes x lines threads on the whole chip (24-48 waves at 432x768), so nothing
+// else hides a load's latency: the r04 kernels fetched a block, waited ~1.5 us for it, ran 16 dependent steps, fetched the next
+// one — 48 such round trips per 768-long sweep, i.e. the sweeps ran at memory LATENCY (profiles/r04_tail_probe.txt: 635 us of WLS
+// per frame against ~30 us of dependent arithmetic).  Same operations in the same order on every element: bit-identical results.
 #define FGS_U 16
-__global__ __launch_bounds__(64) void fgs_coeff_kernel(const float* __restrict__ w, int L, int M, float lambda,
-                                                       float* __restrict__ cp, float* __restrict__ inv) {
+// blockIdx.z = iteration t (r05: the coefficients of ALL iterations come from one launch per direction pair — they depend on the
+// guide and lambda_t only, not on the image being filtered, so nothing orders them behind the solves; r04 launched 2 x T of these
+// latency chains one after the other, ~25 % of the filter's time).  lambda_t arrives in `lam[t]` (the host's float recurrence).
+struct FgsLambdas { float v[8]; };
+__global__ __launch_bounds__(64) void fgs_coeff_kernel(const float* __restrict__ w, int L, int M, FgsLambdas lam, long iter_stride,
+                                                       float* __restrict__ cp, float* __restrict__ inv, float* __restrict__ ap) {
     const int m = blockIdx.x * 64 + threadIdx.x;
     if (m >= M) return;
+    const float lambda = lam.v[blockIdx.z];
     const long off = (long)blockIdx.y * L * M + m;       // blockIdx.y = guide
     const float* wp = w + off;
-    float* cpp = cp + off;
-    float* ivp = inv + off;
+    float* cpp = cp + off + (long)blockIdx.z * iter_stride;
+    float* ivp = inv + off + (long)blockIdx.z * iter_stride;
+    // ap_l = -(a_l inv_l) = (lambda w(l-1,l)) inv_l, the forward sweep's multiplier (ap_0 = 0), for the scan solver; optional
+    float* app = ap ? ap + off + (long)blockIdx.z * iter_stride : nullptr;
+    if (app) app[0] = 0.f;
     float a = 0.f;
     float c = L > 1 ? -lambda * wp[0] : 0.f;
     float iv = 1.f / (1.f - a - c);
     float cprev = c * iv;
     cpp[0] = cprev;
     ivp[0] = iv;
-    int l0 = 1;
-    for (; l0 + FGS_U < L; l0 += FGS_U) {            // full blocks (never contain the last element): no conditions
-        float wk[FGS_U];
+    // full blocks [1 + b U, 1 + (b + 1) U), b < nblk, never contain the last element: no conditions inside
+    const int nblk = L > 1 ? (L - 2) / FGS_U : 0;
+    float wa[FGS_U], wb[FGS_U];
+    auto load = [&](int l0, float (&wk)[FGS_U]) {
 #pragma unroll
         for (int k = 0; k < FGS_U; ++k) wk[k] = wp[(long)(l0 + k) * M];
+    };
+    auto chain = [&](int l0, const float (&wk)[FGS_U]) {
 #pragma unroll
         for (int k = 0; k < FGS_U; ++k) {
             a = c;                                       // a_l = -lambda w(l-1,l) = c_{l-1}
@@ -130,18 +146,141 @@ __global__ __launch_bounds__(64) void fgs_coeff_kernel(const float* __restrict__
             cprev = c * iv;
             cpp[(long)(l0 + k) * M] = cprev;
             ivp[(long)(l0 + k) * M] = iv;
+            if (app) app[(long)(l0 + k) * M] = -a * iv;
         }
+    };
+    if (nblk > 0) load(1, wa);
+    int b = 0;
+    for (; b + 1 < nblk; b += 2) {
+        load(1 + (b + 1) * FGS_U, wb);
+        chain(1 + b * FGS_U, wa);
+        if (b + 2 < nblk) load(1 + (b + 2) * FGS_U, wa);
+        chain(1 + (b + 1) * FGS_U, wb);
     }
-    for (int l = l0; l < L; ++l) {
+    if (b < nblk) chain(1 + b * FGS_U, wa);
+    for (int l = 1 + nblk * FGS_U; l < L; ++l) {
         a = c;
         c = l + 1 < L ? -lambda * wp[(long)l * M] : 0.f;
         iv = 1.f / ((1.f - a - c) - a * cprev);
         cprev = c * iv;
         cpp[(long)l * M] = cprev;
         ivp[(long)l * M] = iv;
+        if (app) app[(long)l * M] = -a * iv;
     }
 }
 
+// ---- r05: the sweeps as SCANS, one wave per line.  d'_l = ap_l d'_{l-1} + f_l inv_l and u_l = -c'_l u_{l+1} + d'_l are first-order
+// linear recurrences, i.e. compositions of affine maps x -> P x + S, which is associative: lane j composes the maps of its E
+// consecutive elements (E = ceil(L / 64) dependent steps), a 6-step shuffle scan composes the lanes' maps, and a second pass of E
+// steps produces the values — 2 E + 6 dependent steps per sweep instead of L, and planes x lines WAVES instead of threads
+// (432x768: 864 / 1536 waves instead of 14 / 24).  The thread-per-line kernel below ran at one wave per SIMD with nothing to
+// overlap its 13 instructions per element: ~20 us per 768-long sweep, 12 sweeps per frame.  |ap_l|, |c'_l| < 1 (diagonally
+// dominant systems), so the composed maps are contractions and the result differs from the sequential sweep by a few ulp
+// (tests/test_tail.py: same tolerance against the oracle as before, and against the fp64 banded solve).
+// Layout: LINE-major ([plane][line][L]: a line is contiguous, lane j of the wave loads element k * 64 + j, coalesced) with the
+// blocked re-distribution (lane j owns elements j E .. j E + E - 1) through LDS at an odd pitch (conflict-free).
+template <int E>
+__global__ __launch_bounds__(256) void fgs_solve_scan_kernel(float* __restrict__ f, const float* __restrict__ ap,
+                                                            const float* __restrict__ inv, const float* __restrict__ cp, int L,
+                                                            int nlines, int planes_per_guide) {
+    constexpr int EP = E | 1;
+    __shared__ float sA[4][64 * EP], sG[4][64 * EP], sC[4][64 * EP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int line_raw = blockIdx.x * 4 + wv;
+    const bool active = line_raw < nlines;
+    const int line = active ? line_raw : nlines - 1;           // (every wave reaches the barriers; inactive ones store nothing)
+    const int plane = blockIdx.y;
+    const long goff = ((long)(plane / planes_per_guide) * nlines + line) * L;
+    float* fp = f + ((long)plane * nlines + line) * L;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int p = k * 64 + lane;
+        float a = 0.f, g = 0.f, c = 0.f;
+        if (p < L) {
+            a = ap[goff + p];
+            g = fp[p] * inv[goff + p];
+            c = cp[goff + p];
+        }
+        const int q = (p / E) * EP + (p % E);
+        sA[wv][q] = a;
+        sG[wv][q] = g;
+        sC[wv][q] = c;
+    }
+    __syncthreads();
+    float a[E], g[E], c[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        a[k] = sA[wv][lane * EP + k];
+        g[k] = sG[wv][lane * EP + k];
+        c[k] = -sC[wv][lane * EP + k];
+    }
+    // forward: the lane's composed map, inclusive scan over the lanes below, then the values
+    float P = 1.f, S = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        S = fmaf(a[k], S, g[k]);
+        P *= a[k];
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float Pp = __shfl_up(P, off), Sp = __shfl_up(S, off);
+        if (lane >= off) {
+            S = fmaf(P, Sp, S);
+            P *= Pp;
+        }
+    }
+    float d = __shfl_up(S, 1);
+    if (lane == 0) d = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        d = fmaf(a[k], d, g[k]);
+        g[k] = d;                                   // g now holds d'
+    }
+    // backward: u_l = c_l u_{l+1} + d'_l (c = -c'), scan over the lanes above
+    P = 1.f, S = 0.f;
+#pragma unroll
+    for (int k = E - 1; k >= 0; --k) {
+        S = fmaf(c[k], S, g[k]);
+        P *= c[k];
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float Pp = __shfl_down(P, off), Sp = __shfl_down(S, off);
+        if (lane + off < 64) {
+            S = fmaf(P, Sp, S);
+            P *= Pp;
+        }
+    }
+    float u = __shfl_down(S, 1);
+    if (lane == 63) u = 0.f;
+#pragma unroll
+    for (int k = E - 1; k >= 0; --k) {
+        u = fmaf(c[k], u, g[k]);
+        sG[wv][lane * EP + k] = u;
+    }
+    __syncthreads();
+    if (!active) return;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int p = k * 64 + lane;
+        if (p < L) fp[p] = sG[wv][(p / E) * EP + (p % E)];
+    }
+}
+
+static void fgs_solve_scan(hipStream_t s, float* f, const float* ap, const float* inv, const float* cp, int L, int nlines, int planes,
+                           int planes_per_guide) {
+    const dim3 grid(cdiv(nlines, 4), planes);
+#define FGS_SCAN(E_) case E_: hipLaunchKernelGGL((fgs_solve_scan_kernel<E_>), grid, dim3(256), 0, s, f, ap, inv, cp, L, nlines, planes_per_guide); break;
+    switch (cdiv(L, 64)) {
+        FGS_SCAN(1) FGS_SCAN(2) FGS_SCAN(3) FGS_SCAN(4) FGS_SCAN(5) FGS_SCAN(6) FGS_SCAN(7) FGS_SCAN(8)
+        FGS_SCAN(9) FGS_SCAN(10) FGS_SCAN(11) FGS_SCAN(12) FGS_SCAN(13) FGS_SCAN(14) FGS_SCAN(15) FGS_SCAN(16)
+        default: break;
+    }
+#undef FGS_SCAN
+}
+#define FGS_SCAN_MAX_L 1024
+
+// (lines longer than FGS_SCAN_MAX_L: one thread per line, as up to r04)
 // solve along axis 0 of f [planes][L][M] in place (planes g*ppg .. use guide g's coefficients); dp: scratch
 __global__ __launch_bounds__(64) void fgs_solve_kernel(float* __restrict__ f, const float* __restrict__ w,
                                                        const float* __restrict__ cp, const float* __restrict__ inv,
@@ -157,51 +296,88 @@ __global__ __launch_bounds__(64) void fgs_solve_kernel(float* __restrict__ f, co
     const float* ivp = inv + goff;
     float dprev = fp[0] * ivp[0];
     dpp[0] = dprev;
-    int l0 = 1;
-    for (; l0 + FGS_U <= L; l0 += FGS_U) {           // full blocks: no conditions, 48 independent loads in flight
-        float ak[FGS_U], fk[FGS_U];
+    // ---- forward sweep: full blocks [1 + b U, 1 + (b + 1) U)
+    const int nblk = (L - 1) / FGS_U;
+    {
+        float iva[FGS_U], wa[FGS_U], fa[FGS_U], ivb[FGS_U], wb[FGS_U], fb[FGS_U];
+        auto load = [&](int l0, float (&ivk)[FGS_U], float (&wk)[FGS_U], float (&fk)[FGS_U]) {
 #pragma unroll
-        for (int k = 0; k < FGS_U; ++k) {
-            const float iv = ivp[(long)(l0 + k) * M];
-            ak[k] = lambda * wp[(long)(l0 + k - 1) * M] * iv;              // -(a_l inv_l), a_l = -lambda w(l-1,l)
-            fk[k] = fp[(long)(l0 + k) * M] * iv;
-        }
+            for (int k = 0; k < FGS_U; ++k) {
+                ivk[k] = ivp[(long)(l0 + k) * M];
+                wk[k] = wp[(long)(l0 + k - 1) * M];
+                fk[k] = fp[(long)(l0 + k) * M];
+            }
+        };
+        auto chain = [&](int l0, const float (&ivk)[FGS_U], const float (&wk)[FGS_U], const float (&fk)[FGS_U]) {
+            float ak[FGS_U], gk[FGS_U];
 #pragma unroll
-        for (int k = 0; k < FGS_U; ++k) {
-            dprev = fmaf(ak[k], dprev, fk[k]);
-            dpp[(long)(l0 + k) * M] = dprev;
+            for (int k = 0; k < FGS_U; ++k) {
+                ak[k] = lambda * wk[k] * ivk[k];                            // -(a_l inv_l), a_l = -lambda w(l-1,l)
+                gk[k] = fk[k] * ivk[k];
+            }
+#pragma unroll
+            for (int k = 0; k < FGS_U; ++k) {
+                dprev = fmaf(ak[k], dprev, gk[k]);
+                dpp[(long)(l0 + k) * M] = dprev;
+            }
+        };
+        if (nblk > 0) load(1, iva, wa, fa);
+        int b = 0;
+        for (; b + 1 < nblk; b += 2) {
+            load(1 + (b + 1) * FGS_U, ivb, wb, fb);
+            chain(1 + b * FGS_U, iva, wa, fa);
+            if (b + 2 < nblk) load(1 + (b + 2) * FGS_U, iva, wa, fa);
+            chain(1 + (b + 1) * FGS_U, ivb, wb, fb);
         }
+        if (b < nblk) chain(1 + b * FGS_U, iva, wa, fa);
     }
-    for (int l = l0; l < L; ++l) {
+    for (int l = 1 + nblk * FGS_U; l < L; ++l) {
         const float iv = ivp[(long)l * M];
         dprev = fmaf(lambda * wp[(long)(l - 1) * M] * iv, dprev, fp[(long)l * M] * iv);
         dpp[(long)l * M] = dprev;
     }
+    // ---- backward sweep: full blocks (L - 2 - b U) downwards
     float u = dprev;
     fp[(long)(L - 1) * M] = u;
-    int l1 = L - 2;
-    for (; l1 - (FGS_U - 1) >= 0; l1 -= FGS_U) {
-        float ck[FGS_U], dk[FGS_U];
+    const int nbb = (L - 1) / FGS_U;
+    {
+        float ca[FGS_U], da[FGS_U], cb[FGS_U], db[FGS_U];
+        auto load = [&](int l1, float (&ck)[FGS_U], float (&dk)[FGS_U]) {
 #pragma unroll
-        for (int k = 0; k < FGS_U; ++k) {
-            ck[k] = cpp[(long)(l1 - k) * M];
-            dk[k] = dpp[(long)(l1 - k) * M];
-        }
+            for (int k = 0; k < FGS_U; ++k) {
+                ck[k] = cpp[(long)(l1 - k) * M];
+                dk[k] = dpp[(long)(l1 - k) * M];
+            }
+        };
+        auto chain = [&](int l1, const float (&ck)[FGS_U], const float (&dk)[FGS_U]) {
 #pragma unroll
-        for (int k = 0; k < FGS_U; ++k) {
-            u = fmaf(-ck[k], u, dk[k]);
-            fp[(long)(l1 - k) * M] = u;
+            for (int k = 0; k < FGS_U; ++k) {
+                u = fmaf(-ck[k], u, dk[k]);
+                fp[(long)(l1 - k) * M] = u;
+            }
+        };
+        if (nbb > 0) load(L - 2, ca, da);
+        int b = 0;
+        for (; b + 1 < nbb; b += 2) {
+            load(L - 2 - (b + 1) * FGS_U, cb, db);
+            chain(L - 2 - b * FGS_U, ca, da);
+            if (b + 2 < nbb) load(L - 2 - (b + 2) * FGS_U, ca, da);
+            chain(L - 2 - (b + 1) * FGS_U, cb, db);
         }
+        if (b < nbb) chain(L - 2 - b * FGS_U, ca, da);
     }
-    for (int l = l1; l >= 0; --l) {
+    for (int l = L - 2 - nbb * FGS_U; l >= 0; --l) {
         u = fmaf(-cpp[(long)l * M], u, dpp[(long)l * M]);
         fp[(long)l * M] = u;
     }
 }
 
-extern "C" size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t n_guides, int32_t planes_per_guide) {
-    // per guide: wv, wh_t and (c', 1/m) of the row and of the column system; per plane: transposed image + d'
-    return sizeof(float) * ((size_t)6 * n_guides * H * W + (size_t)2 * n_guides * planes_per_guide * H * W);
+#define FGS_MAX_ITER 8
+extern "C" size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t n_guides, int32_t planes_per_guide, int32_t num_iter) {
+    // per guide: wv, wh_t; (c', 1/m, ap) of every iteration in the coefficient kernel's layout (one direction at a time) and in the
+    // line-major layout of both directions; per plane: the transposed image (+ d' of the thread-per-line fall-back)
+    if (num_iter < 1) num_iter = 1;
+    return sizeof(float) * ((size_t)(2 + 9 * num_iter) * n_guides * H * W + (size_t)2 * n_guides * planes_per_guide * H * W);
 }
 
 extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_guides, int32_t planes_per_guide,
@@ -211,20 +387,20 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
     DVC_REQUIRE(guide && src && dst && workspace && n_guides > 0 && planes_per_guide > 0 && H > 0 && W > 0,
                 "dvc_fgs_filter: bad argument");
     const int planes = n_guides * planes_per_guide;
-    DVC_REQUIRE(num_iter >= 1 && num_iter <= 8 && sigma_color > 0.f && lambda >= 0.f, "dvc_fgs_filter: bad parameters");
-    DVC_REQUIRE(workspace_bytes >= dvc_fgs_workspace_bytes(H, W, n_guides, planes_per_guide),
+    DVC_REQUIRE(num_iter >= 1 && num_iter <= FGS_MAX_ITER && sigma_color > 0.f && lambda >= 0.f, "dvc_fgs_filter: bad parameters");
+    DVC_REQUIRE(workspace_bytes >= dvc_fgs_workspace_bytes(H, W, n_guides, planes_per_guide, num_iter),
                 "dvc_fgs_filter: workspace too small");
     DVC_REQUIRE((long)H * W < (1L << 30), "dvc_fgs_filter: image too large");
     hipStream_t s = (hipStream_t)stream;
     const size_t HW = (size_t)H * W, GHW = (size_t)n_guides * HW;
+    const size_t IT = (size_t)num_iter * GHW;
     float* wv = reinterpret_cast<float*>(workspace);
     float* wh_t = wv + GHW;
-    float* cp_r = wh_t + GHW;   // row system (lines of length W, on the transposed image)
-    float* iv_r = cp_r + GHW;
-    float* cp_c = iv_r + GHW;   // column system
-    float* iv_c = cp_c + GHW;
-    float* tr = iv_c + GHW;
-    float* dp = tr + planes * HW;
+    float* tmp = wh_t + GHW;        // (c', 1/m, ap) x iterations in the coefficient kernel's [L][M] layout: rows, then columns
+    float* row_lm = tmp + 3 * IT;   // the same, line-major: row system [guide][H][W]
+    float* col_lm = row_lm + 3 * IT;  //                      column system [guide][W][H]
+    float* tr = col_lm + 3 * IT;    // transposed image [plane][W][H]
+    float* dp = tr + planes * HW;   // (fall-back only)
     hipLaunchKernelGGL(fgs_weights_kernel, dim3(cdiv((int)HW, 1024), n_guides), dim3(256), 0, s, guide, H, W,
                        1.0f / sigma_color, wv, wh_t);
     DVC_CHECK_LAUNCH("dvc_fgs_filter(weights)");
@@ -233,21 +409,46 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
         DVC_REQUIRE(e == hipSuccess, "dvc_fgs_filter: copy failed: %s", hipGetErrorString(e));
     }
     double lam = 1.5 * (double)lambda * pow(4.0, num_iter - 1) / (pow(4.0, num_iter) - 1.0);
-    float lam_f = (float)lam;
+    FgsLambdas lams;
+    lams.v[0] = (float)lam;
+    for (int it = 1; it < FGS_MAX_ITER; ++it) lams.v[it] = lams.v[it - 1] * lambda_attenuation;      // (the float recurrence of r01-r04)
     const dim3 tgrid_fwd(cdiv(W, 32), cdiv(H, 32), planes), tgrid_bwd(cdiv(H, 32), cdiv(W, 32), planes);
+    const bool scan = H <= FGS_SCAN_MAX_L && W <= FGS_SCAN_MAX_L;
+    const int ncoef = 3 * num_iter * n_guides;      // planes of one direction's coefficient set
+    // elimination coefficients of every iteration: one launch per direction (all chains in flight together), then — scan solver —
+    // one transposition of the whole set into the line-major layout
+    // rows: lines of length W (the row system's [L = W][M = H] layout is the transposed image's)
+    hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(H, 64), n_guides, num_iter), dim3(64), 0, s, wh_t, W, H, lams, (long)GHW, tmp, tmp + IT,
+                       scan ? tmp + 2 * IT : nullptr);
+    if (scan) {
+        hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(H, 32), cdiv(W, 32), ncoef), dim3(256), 0, s, tmp, W, H, row_lm);
+        hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(W, 64), n_guides, num_iter), dim3(64), 0, s, wv, H, W, lams, (long)GHW, tmp, tmp + IT,
+                           tmp + 2 * IT);
+        hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(W, 32), cdiv(H, 32), ncoef), dim3(256), 0, s, tmp, H, W, col_lm);
+    } else {
+        // (fall-back: the thread-per-line solver reads the [L][M] layouts; rows' set stays in tmp, columns' goes to row_lm)
+        hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(W, 64), n_guides, num_iter), dim3(64), 0, s, wv, H, W, lams, (long)GHW, row_lm,
+                           row_lm + IT, (float*)nullptr);
+    }
+    DVC_CHECK_LAUNCH("dvc_fgs_filter(coefficients)");
     for (int it = 0; it < num_iter; ++it) {
-        hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(H, 64), n_guides), dim3(64), 0, s, wh_t, W, H, lam_f, cp_r, iv_r);
-        hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(W, 64), n_guides), dim3(64), 0, s, wv, H, W, lam_f, cp_c, iv_c);
-        // rows: every image row is a line of length W; in the transposed image [W][H] it runs along axis 0
-        hipLaunchKernelGGL(transpose_kernel, tgrid_fwd, dim3(256), 0, s, dst, H, W, tr);
-        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(H, 64), planes), dim3(64), 0, s, tr, wh_t, cp_r, iv_r, W, H,
-                           planes_per_guide, lam_f, dp);
-        hipLaunchKernelGGL(transpose_kernel, tgrid_bwd, dim3(256), 0, s, tr, W, H, dst);
-        // columns
-        hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(W, 64), planes), dim3(64), 0, s, dst, wv, cp_c, iv_c, H, W,
-                           planes_per_guide, lam_f, dp);
+        if (scan) {
+            // rows in place on the image; columns on the transposed image
+            fgs_solve_scan(s, dst, row_lm + 2 * IT + it * GHW, row_lm + IT + it * GHW, row_lm + it * GHW, W, H, planes, planes_per_guide);
+            hipLaunchKernelGGL(transpose_kernel, tgrid_fwd, dim3(256), 0, s, dst, H, W, tr);
+            fgs_solve_scan(s, tr, col_lm + 2 * IT + it * GHW, col_lm + IT + it * GHW, col_lm + it * GHW, H, W, planes, planes_per_guide);
+            hipLaunchKernelGGL(transpose_kernel, tgrid_bwd, dim3(256), 0, s, tr, W, H, dst);
+        } else {
+            // rows: every image row is a line of length W; in the transposed image [W][H] it runs along axis 0
+            hipLaunchKernelGGL(transpose_kernel, tgrid_fwd, dim3(256), 0, s, dst, H, W, tr);
+            hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(H, 64), planes), dim3(64), 0, s, tr, wh_t, tmp + it * GHW, tmp + IT + it * GHW, W, H,
+                               planes_per_guide, lams.v[it], dp);
+            hipLaunchKernelGGL(transpose_kernel, tgrid_bwd, dim3(256), 0, s, tr, W, H, dst);
+            // columns
+            hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(W, 64), planes), dim3(64), 0, s, dst, wv, row_lm + it * GHW, row_lm + IT + it * GHW, H, W,
+                               planes_per_guide, lams.v[it], dp);
+        }
         DVC_CHECK_LAUNCH("dvc_fgs_filter(solve)");
-        lam_f = lam_f * lambda_attenuation;
     }
     return 0;
 }

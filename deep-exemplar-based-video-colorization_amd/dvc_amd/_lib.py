@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DVC_DEBUG_LIB=1 (tools/ only) loads the -DDVC_DEBUG build, the only one that carries the dvc_debug_* hooks
 DEBUG_BUILD = os.environ.get("DVC_DEBUG_LIB", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "libdvc_hip_debug.so" if DEBUG_BUILD else "libdvc_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -76,7 +76,7 @@ SIGNATURES = {
     "dvc_pack_color_input": (ctypes.c_int, [_VP, c_i64, _VP, _VP, _VP, c_i64, _VP, c_i64, c_i32, c_i32, _VP, _VP]),
     "dvc_upsample_bilinear2x": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP]),
     "dvc_lum_guide_u8": (ctypes.c_int, [_VP, c_i64, _VP, _VP]),
-    "dvc_fgs_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32]),
+    "dvc_fgs_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "dvc_fgs_filter": (ctypes.c_int, [_VP, _VP, c_i32, c_i32, c_i32, c_i32, ctypes.c_float, ctypes.c_float, c_i32,
                                       ctypes.c_float, _VP, _VP, ctypes.c_size_t, _VP]),
     "dvc_lab2rgb_u8": (ctypes.c_int, [_VP, _VP, c_i32, c_i32, _VP, _VP]),

@@ -159,4 +159,18 @@ def colorvidnet_param_shapes(ic=7):
 # algorithm choice because their Winograd rounding moves the frame's ab output the most per microsecond saved
 # (tools/engine_sensitivity.py on the MI355X, profiles/r05_engine_sensitivity.txt).  Names = state_dict prefixes with the
 # network in front ("vgg.", "warp.", "cvn.").
-DIRECT_LAYERS = frozenset()
+# What the measurements say (r05, MI355X, 216x384, plain seed-0 weights, T = 1e-10, 10 frames without arg-max flips against the
+# fp64 oracle, CPU fp32 = 1.00; profiles/r05_engine_map_eval.txt):
+#   every eligible layer on Winograd ("speed")        rms 1.10  mean 1.09  q999 1.16  max 1.92
+#   the whole FRONT END direct, ColorVidNet Winograd  rms 1.09  — the front end's engine does not matter: at T = 1e-10 it reaches
+#                                                       ColorVidNet only through the similarity map's last bits and the arg-max
+#   ColorVidNet direct, front end Winograd            rms 0.81  — the same as everything direct (0.82)
+#   conv2_1, conv2_2 direct                           rms 0.99  mean 0.98  q999 1.02  max 1.72
+#   conv1_1.2 .. conv2_2 direct                       rms 0.91  mean 0.91  q999 0.94  max 1.26
+#   conv1_1.2 .. conv3_3 direct (this map)            rms 0.85  mean 0.85  q999 0.85  max 0.91   (worst frame: max 1.06)
+# The excess sits in ColorVidNet's first seven 3x3 layers (an error there is amplified by everything behind it: perturbation
+# energy per layer falls 30x from conv1_2 to conv4_3, profiles/r05_engine_sensitivity.txt, while Winograd's own rounding is
+# 1.1-2.2x the direct sum's on every layer, profiles/r05_engine_layer_error.txt); they cost 107-135 us of convolution time per
+# frame on the direct engine.  Forcing a larger split over input channels on the Winograd kernel (shorter accumulation chains)
+# buys less accuracy per microsecond than the direct engine on every one of them (same file).
+DIRECT_LAYERS = frozenset(("cvn.conv1_1.2", "cvn.conv1_2", "cvn.conv2_1", "cvn.conv2_2", "cvn.conv3_1", "cvn.conv3_2", "cvn.conv3_3"))

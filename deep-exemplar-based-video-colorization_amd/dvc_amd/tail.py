@@ -54,7 +54,7 @@ def fgs_filter(guide_u8, src, lambda_value=500.0, sigma_color=4.0, num_iter=3, l
     if tuple(guide_u8.shape[-2:]) != (H, W) or (batched and (src.dim() != 4 or src.shape[0] != G)):
         raise RuntimeError(f"dvc_amd: guide {tuple(guide_u8.shape)} does not fit src {tuple(src.shape)}")
     dst = torch.empty_like(src)
-    ws = _workspace(src.device, lib.dvc_fgs_workspace_bytes(H, W, G, ppg), "fgs")
+    ws = _workspace(src.device, lib.dvc_fgs_workspace_bytes(H, W, G, ppg, int(num_iter)), "fgs")
     _lib.check(lib.dvc_fgs_filter(ctypes.c_void_p(guide_u8.data_ptr()), _p(src), G, ppg, H, W, float(lambda_value),
                                   float(sigma_color), int(num_iter), float(lambda_attenuation), _p(dst),
                                   ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "dvc_fgs_filter")

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 14
+#define DVC_ABI_VERSION 15
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -270,7 +270,7 @@ int dvc_lum_guide_u8(const float* L_centered, int64_t n, uint8_t* guide, dvcStre
  * (4^T - 1) * lambda, weights exp(-|dg| / sigma_color).  OpenCV's defaults: num_iter 3, attenuation 0.25.
  * Several frames (guides) are filtered by one call: planes g*planes_per_guide.. use guide g.  dst may be src.
  * Parity unpinned (opencv-contrib is absent from the build image; see oracle/tail_oracle.py). */
-size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t n_guides, int32_t planes_per_guide);
+size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t n_guides, int32_t planes_per_guide, int32_t num_iter);
 int dvc_fgs_filter(const uint8_t* guide /* [n_guides][H][W] */, const float* src /* [n_guides*planes_per_guide][H][W] */,
                    int32_t n_guides, int32_t planes_per_guide, int32_t H, int32_t W, float lambda, float sigma_color,
                    int32_t num_iter, float lambda_attenuation, float* dst, void* workspace, size_t workspace_bytes,

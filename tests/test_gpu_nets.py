@@ -220,16 +220,18 @@ def conv_algo(request):
     ops.set_conv_algo(old)
 
 
-# With plain random weights the network amplifies rounding noise ~70x (dvc_amd/synth.py), so these two tests bound the GPU's
+# With plain random weights the network amplifies rounding noise ~70x (dvc_amd/synth.py), so these tests bound the GPU's
 # distance from the fp64 truth by a multiple of the reference-equivalent CPU fp32 run's distance.  The direct engine sits
-# at or below the CPU run; Winograd F(2x2,3x3) carries 2.3x the rounding error of a direct fp32 sum per layer
-# (csrc/conv_wino_kernel.h, measured) — the same trade cuDNN makes for the reference under cudnn.benchmark (test.py:140) —
-# so its worst-case statistics get 2.5x, its mean still 1.5x.  The literal 1e-3 claim is asserted on the well-conditioned
-# weights in tests/test_gpu_e2e.py, with the default (Winograd) algorithm.
-WORST_CASE_FACTOR = {"direct": 1.5, "auto": 2.5}
+# at or below the CPU run; Winograd F(2x2,3x3) carries 1.1-2.2x the rounding error of a direct fp32 sum per layer
+# (profiles/r05_engine_layer_error.txt) — the same trade cuDNN makes for the reference under cudnn.benchmark (test.py:140).
+# r05: the default choice ("auto") keeps the layers where that matters on the direct engine (arch.DIRECT_LAYERS, measured with
+# tools/engine_sensitivity.py) and is held to the SAME factor as the direct engine; "speed" (the geometry rule alone, what "auto"
+# meant up to r04) keeps the looser factor and is reported next to it.  The literal 1e-3 claim is asserted on the well-conditioned
+# weights in tests/test_gpu_e2e.py, with the default algorithm.
+WORST_CASE_FACTOR = {"direct": 1.5, "auto": 1.5, "speed": 2.5}
 
 
-@pytest.mark.parametrize("conv_algo", ["auto", "direct"], indirect=True)
+@pytest.mark.parametrize("conv_algo", ["auto", "direct", "speed"], indirect=True)
 @pytest.mark.parametrize("H,W", [(48, 80), (216, 384)])
 def test_colorvidnet(nets, weights, H, W, conv_algo):
     from oracle import dvc_oracle as O
@@ -269,7 +271,7 @@ def _run_clip(nets, H, W, nf, T, cache):
     return outs, warped
 
 
-@pytest.mark.parametrize("conv_algo", ["auto", "direct"], indirect=True)
+@pytest.mark.parametrize("conv_algo", ["auto", "direct", "speed"], indirect=True)
 @pytest.mark.parametrize("name", ["small_48x80_T1e-10", "small_40x64_T0.01", "full_216x384_T1e-10"])
 def test_frame_colorization_vs_reference_golden(nets, weights, golden_dir, name, conv_algo):
     """End-to-end vs outputs recorded from the UNMODIFIED reference (oracle/pin_reference.py), under both convolution
@@ -291,7 +293,8 @@ def test_frame_colorization_vs_reference_golden(nets, weights, golden_dir, name,
         oracle/pin_reference.py) on the golden warped colours / similarity / previous frame with the flipped rows' 4x4
         blocks carrying the colour the HIP path chose.  Without a flip that evaluation IS the golden `ab`;
       * the statistics every frame must meet: mean < 2e-3, p99 < 1e-2, and max below WORST_CASE_FACTOR x 1e-2 — 1.5e-2 for the
-        direct engine and 2.5e-2 for Winograd (the reference's own fp32-vs-fp64 worst case on this network is 6.4e-3,
+        direct engine and, since r05, for the default choice (the error-aware engine map); 2.5e-2 for "speed" = Winograd wherever
+        the geometry allows (the reference's own fp32-vs-fp64 worst case on this network is 6.4e-3,
         test_colorvidnet, and the golden carries that error too; the MAX over 166k values of a chaotic network's error field
         moves by 50 % when one front-end layer rounds differently — measured r03 / r04: 1.13e-2 / 1.69e-2 with Winograd,
         7.9e-3 / 8.4e-3 direct — so the factor the less accurate engine costs is asserted on the worst case loosely and on
@@ -366,15 +369,16 @@ def test_frame_colorization_vs_reference_golden(nets, weights, golden_dir, name,
 
 @pytest.mark.parametrize("H,W,T", [(48, 80, 1e-10), (40, 64, 0.01), (216, 384, 1e-10)])
 def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights, H, W, T):
-    """The honest form of the "ab within 1e-3" claim with the chaotic random weights (SURVEY.md §7 hard part 1): GPU-fp32
-    vs the fp64 truth, next to the reference-equivalent CPU-fp32 vs the same truth, under BOTH convolution engines in one
-    test.  Pass = within 1e-3, or no further from the truth than 1.5x the CPU fp32 run in the mean and WORST_CASE_FACTOR x in
-    the 99.9th percentile.  r04: the price of the Winograd engine is asserted as a ratio between the two engines' errors
-    against the same truth — 99.9th percentile <= 2.5x, mean <= 1.6x the direct engine's, maximum <= 4x the CPU fp32 run's
-    (measured at 216x384, r03 / r04: max 1.10e-2 / 1.66e-2 vs 4.97e-3 direct and 5.94e-3 CPU fp32 — the maximum of a chaotic
-    network's error field moves by 50 % when one front-end layer rounds differently, hence the ratio is asserted on the
-    percentile —, q999 4.8e-3 / 7.0e-3 vs 3.2e-3, mean 8.0e-4 / 8.3e-4 vs 6.0e-4) — and the direct engine must be at or
-    below the CPU fp32 run's worst case."""
+    """The honest form of the "ab within 1e-3" claim with the chaotic random weights (SURVEY.md §7 hard part 1, §8(c): "GPU-fp32
+    vs fp64 oracle reported next to CPU-fp32 vs fp64 oracle (must be <= the CPU figure)"): GPU-fp32 vs the fp64 truth, next to the
+    reference-equivalent CPU-fp32 vs the same truth, under the default engine choice ("auto" = what bench.py times), the direct
+    engine and the geometry-only Winograd rule ("speed") in one test.
+
+    r05 bar (r04 review, item 1): at test.py's temperature the TIMED engine must be no further from the truth than the CPU fp32
+    run — q999 <= 1.0x, mean <= 1.0x, max <= 1.25x the CPU run's (the maximum of 166k values of a chaotic network's error field
+    is one pixel's lottery; measured over 10 frames: worst frame 1.06, pooled 0.91) — and so must the direct engine; "speed"
+    is reported, with the price it pays (r04: q999 1.8x, max 2.8x at 216x384) bounded at WORST_CASE_FACTOR["speed"].
+    At the soft temperature the correlation's 1/T dominates both engines' errors (bounded against the CPU run at 1.5x)."""
     from dvc_amd import ops, synth
     from oracle import dvc_oracle as O
     sd32 = weights
@@ -393,7 +397,7 @@ def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights, H, W, T):
     errs = {}
     old = ops.conv_algo()
     try:
-        for algo in ("auto", "direct"):
+        for algo in ("auto", "direct", "speed"):
             ops.set_conv_algo(algo)
             outs, warped = _run_clip(nets, H, W, 1, T, cache=True)
             e_gpu = (outs[0].double().cpu() - ab64).abs()
@@ -405,6 +409,11 @@ def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights, H, W, T):
             assert e_gpu.mean().item() < max(1e-3, 1.5 * e_cpu.mean().item())
             assert q(e_gpu) < max(1e-3, WORST_CASE_FACTOR[algo] * q(e_cpu))
             assert w_gpu.max().item() < max(1e-3, 2.0 * w_cpu.max().item())
+            if T < 1e-6 and algo != "speed":
+                # the bar: the engine bench.py times (and the direct engine) at or below the reference's own fp32 error
+                assert q(e_gpu) <= 1.0 * q(e_cpu), (algo, q(e_gpu), q(e_cpu))
+                assert e_gpu.mean().item() <= 1.0 * e_cpu.mean().item(), (algo, e_gpu.mean().item(), e_cpu.mean().item())
+                assert e_gpu.max().item() <= 1.25 * e_cpu.max().item(), (algo, e_gpu.max().item(), e_cpu.max().item())
             if H <= 64 and algo == "auto":
                 # report only: how a FREE-RUNNING second frame (IA_last = own previous prediction) diverges
                 fr1 = synth.synth_lab(synth.FRAME_SEED0 + 1, H, W)
@@ -417,15 +426,59 @@ def test_e2e_error_vs_fp64_oracle_next_to_cpu_fp32(nets, weights, H, W, T):
                        f"| CPU32-vs-fp64 mean={(a32.double() - a64).abs().mean():.2e}")
     finally:
         ops.set_conv_algo(old)
-    r_max = errs["auto"].max().item() / errs["direct"].max().item()
-    r_q = q(errs["auto"]) / q(errs["direct"])
-    r_mean = errs["auto"].mean().item() / errs["direct"].mean().item()
-    report(f"e2e vs fp64 {H}x{W} T={T}: Winograd / direct error ratio max {r_max:.2f} q999 {r_q:.2f} mean {r_mean:.2f}; direct / CPU32 max "
-           f"{errs['direct'].max().item() / e_cpu.max().item():.2f}; Winograd / CPU32 max {errs['auto'].max().item() / e_cpu.max().item():.2f}")
-    if T < 1e-6:        # (at the soft temperature the correlation's 1/T dominates both engines' errors)
-        assert r_q <= 2.5 and r_mean <= 1.6, (r_q, r_mean)
-        assert errs["auto"].max().item() <= 4.0 * e_cpu.max().item()
-        assert errs["direct"].max().item() <= 1.2 * e_cpu.max().item()
+    ratio = lambda a, b: (errs[a].max().item() / b.max().item(), q(errs[a]) / q(b), errs[a].mean().item() / b.mean().item())   # noqa: E731
+    for a in ("auto", "direct", "speed"):
+        r = ratio(a, e_cpu)
+        report(f"e2e vs fp64 {H}x{W} T={T}: {a} / CPU32 error ratio max {r[0]:.2f} q999 {r[1]:.2f} mean {r[2]:.2f}")
+    r = ratio("speed", errs["direct"])
+    report(f"e2e vs fp64 {H}x{W} T={T}: speed (Winograd wherever the geometry allows) / direct error ratio max {r[0]:.2f} q999 {r[1]:.2f} "
+           f"mean {r[2]:.2f}")
+    if T < 1e-6:
+        assert r[1] <= 2.5 and r[2] <= 1.6, r
+        assert errs["speed"].max().item() <= 4.0 * e_cpu.max().item()
+
+
+def test_timed_engine_no_further_from_fp64_than_cpu_fp32_pooled_216x384(nets, weights):
+    """The same comparison pooled over several frames (one frame's error maximum is a lottery: over 10 frames the per-frame
+    max ratio of the SAME engine ranges 0.5 ... 1.1): frames 1000..1005 as first frames of a clip at 216x384, T = 1e-10, the
+    default engine against the fp64 oracle next to CPU fp32.  Frames on which an arg-max differs from the truth's (a near-tie
+    row: the golden tests deal with those) are left out for both sides; at least three must remain.  Pooled rms, mean and q999
+    <= 1.0x the CPU run's, pooled max <= 1.25x."""
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    from oracle import dvc_oracle as O
+    H, W, T = 216, 384, 1e-10
+    sd64 = tuple(O.to_dtype(s, torch.float64) for s in weights)
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
+    cc = ClipColorizer(*nets, temperature=T)
+    cc.set_exemplar(IB.cuda())
+    eg, ec, used = [], [], []
+    with torch.no_grad():
+        fB32 = O.exemplar_features(IB, weights[0])
+        fB64 = O.exemplar_features(IB.double(), sd64[0])
+    for seed in range(synth.FRAME_SEED0, synth.FRAME_SEED0 + 6):
+        fr = synth.synth_lab(seed, H, W)
+        z = torch.zeros_like(fr)
+        with torch.no_grad():
+            ab32, nl32, _ = O.frame_colorization(fr, IB, z, fB32, *weights, temperature=T)
+            ab64, nl64, _ = O.frame_colorization(fr.double(), IB.double(), z.double(), fB64, *sd64, temperature=T)
+        ab, nl = cc.frame(fr.cuda(), z.cuda())
+        if (nl.double().cpu() - nl64).abs().max().item() > 1e-3 or (nl32.double() - nl64).abs().max().item() > 1e-3:
+            report(f"pooled e2e vs fp64: frame seed {seed} left out (an arg-max differs from the fp64 truth's)")
+            continue
+        used.append(seed)
+        eg.append((ab.double().cpu() - ab64).abs())
+        ec.append((ab32.double() - ab64).abs())
+    assert len(used) >= 3, used
+    eg, ec = torch.cat(eg), torch.cat(ec)
+    q = lambda t: np.quantile(t.numpy(), 0.999)       # noqa: E731
+    rms = lambda t: t.pow(2).mean().sqrt().item()     # noqa: E731
+    report(f"pooled e2e vs fp64 216x384 T=1e-10 over frames {used}: GPU(auto) max={eg.max():.2e} q999={q(eg):.2e} mean={eg.mean():.2e} "
+           f"rms={rms(eg):.2e} | CPU32 max={ec.max():.2e} q999={q(ec):.2e} mean={ec.mean():.2e} rms={rms(ec):.2e} | ratios max "
+           f"{eg.max().item() / ec.max().item():.2f} q999 {q(eg) / q(ec):.2f} mean {eg.mean().item() / ec.mean().item():.2f} "
+           f"rms {rms(eg) / rms(ec):.2f}")
+    assert rms(eg) <= rms(ec) and eg.mean().item() <= ec.mean().item() and q(eg) <= q(ec)
+    assert eg.max().item() <= 1.25 * ec.max().item()
 
 
 def test_clip_recurrence_cached_equals_uncached_and_deterministic(nets):

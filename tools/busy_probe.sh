@@ -2,7 +2,7 @@
 # How busy is the GPU under the per-frame loop (one stream)?  rocprofv3 kernel trace of `bench.py --lookahead 0`, then the
 # union of kernel intervals over the last second of the trace.
 export TMPDIR=/tmp; mkdir -p gpurun_out; rm -rf gpurun_out/busy
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/busy -o t -- python bench.py --lookahead 0 --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/busy_bench.json 2> gpurun_out/busy.err
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/busy -o t -- python bench.py --lookahead 0 --steps 40 --warmup 5 --no-cpu-baseline --no-speed-leg > gpurun_out/busy_bench.json 2> gpurun_out/busy.err
 python - <<'PY'
 import csv, glob, json
 f = glob.glob("gpurun_out/busy/**/t_kernel_trace.csv", recursive=True)[0]

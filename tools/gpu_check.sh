@@ -24,8 +24,8 @@ fi
 if [[ $what == all || $what == prof ]]; then
   rm -rf gpurun_out/prof
   export DVC_AUTOTUNE_CACHE=$PWD/gpurun_out/autotune.json
-  timeout 200 python bench.py --steps 5 --warmup 3 --no-cpu-baseline --refs 0 --clips 0 > /dev/null 2>&1   # fills the autotune cache
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o trace -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --refs 0 --clips 0 > gpurun_out/prof_bench.json 2> gpurun_out/prof.err
+  timeout 200 python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-speed-leg --refs 0 --clips 0 > /dev/null 2>&1   # fills the autotune cache
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o trace -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-speed-leg --refs 0 --clips 0 > gpurun_out/prof_bench.json 2> gpurun_out/prof.err
   echo "prof rc=$?"; cat gpurun_out/prof_bench.json
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
   [[ -n "$f" ]] && head -n 40 "$f"
@@ -35,6 +35,7 @@ fi
 unset DVC_AUTOTUNE_CACHE
 if [[ $what == pmc || $what == all2 ]]; then
   rm -rf gpurun_out/pmc*; 
+  sha256sum deep-exemplar-based-video-colorization_amd/csrc/corr.hip | cut -c1-16 > gpurun_out/corr_hip_sha.txt
   rocprofv3 -L > gpurun_out/counters_list.txt 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pmc1 -o p -- python tools/prof_kernels.py > gpurun_out/pmc1.log 2>&1; echo "pmc1 rc=$?"
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc2 -o p -- python tools/prof_kernels.py > gpurun_out/pmc2.log 2>&1; echo "pmc2 rc=$?"

@@ -5,6 +5,7 @@ profiles/<round>_bench_line.json (the JSON line printed under the profiler) and
 profiles/<round>_pmc_summary.md (derived metrics from the separate --pmc passes)."""
 import collections
 import csv
+import hashlib
 import json
 import os
 import shutil
@@ -87,7 +88,13 @@ for k, v in agg.items():
                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/prof_kernels.py; "
                          "read = 2 x FETCH_SIZE (gfx950: 64 B tallied per 128-B request, MI355X_MICROARCH.md), averaged over the "
                          "launches of the kernel",
-               "measured_on": f"{tag} (profiles/{tag}_pmc_summary.md)"}
+               "measured_on": f"{tag} (profiles/{tag}_pmc_summary.md)",
+               # bench.py refuses this file once csrc/corr.hip no longer is the source the PMC passes ran (r04 review, item 5)
+               # (the hash taken ON THE GPU BOX next to the passes, tools/gpu_final.sh; of the local source as a fall-back)
+               "corr_hip_sha256_16": (open(os.path.join(G, "corr_hip_sha.txt")).read().strip()[:16]
+                                      if os.path.exists(os.path.join(G, "corr_hip_sha.txt")) else
+                                      hashlib.sha256(open(os.path.join(ROOT, "deep-exemplar-based-video-colorization_amd", "csrc",
+                                                                       "corr.hip"), "rb").read()).hexdigest()[:16])}
         json.dump(rec, open(os.path.join(P, "corr_traffic.json"), "w"))
         print("corr traffic:", rec["bytes_per_launch"], "bytes per launch")
 print("\n".join(lines[-8:]))
