@@ -19,3 +19,7 @@ rm -rf gpurun_out/corrprof; timeout 300 rocprofv3 --kernel-trace --stats --outpu
 timeout 300 python tools/refs_chain_probe.py > gpurun_out/refs_chain_probe.txt 2>&1; tail -3 gpurun_out/refs_chain_probe.txt
 timeout 600 python tools/training_side_probe.py > gpurun_out/training_side_probe.txt 2>&1; tail -3 gpurun_out/training_side_probe.txt
 find gpurun_out -name "*kernel_trace.csv" -size +6M -delete
+# r05: the tail probe (FGS scan solver), the bf16 bench line's own kernel trace (its roofline block cites it)
+timeout 300 python tools/tail_probe.py > gpurun_out/tail_probe.txt 2>&1; tail -9 gpurun_out/tail_probe.txt
+rm -rf gpurun_out/prof_bf16; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bf16 -o trace -- python bench.py --steps 20 --warmup 3 --corr bf16 --no-cpu-baseline --no-speed-leg --refs 0 --clips 0 > gpurun_out/prof_bf16_bench.json 2> gpurun_out/prof_bf16.err; echo "prof bf16 rc=$?"
+find gpurun_out -name "*kernel_trace.csv" -size +6M -delete

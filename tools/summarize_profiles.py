@@ -26,6 +26,17 @@ if os.path.exists(os.path.join(G, "tune_conv.json")):
 if os.path.exists(os.path.join(G, "box.txt")):
     shutil.copy(os.path.join(G, "box.txt"), os.path.join(P, f"{tag}_box.txt"))
 
+# everything else the round's DESIGN.md / README cite, copied under the round's tag when the GPU run produced it
+for src, dst in (("bench_432x768.json", "bench_line_432x768.json"), ("bench_bf16.json", "bench_line_bf16_corr.json"),
+                 ("bench_torchrun1.json", "bench_line_torchrun_1rank.json"), ("conv_algo_sweep.txt", "conv_algo_sweep.txt"),
+                 ("busy_probe.txt", "busy_probe.txt"), ("corr_roofline_probe.txt", "corr_roofline_probe.txt"),
+                 ("refs_chain_probe.txt", "refs_chain_probe.txt"), ("training_side_probe.txt", "training_side_probe.txt"),
+                 ("tail_probe.txt", "tail_probe.txt"), ("test_report.txt", "test_report_parity.txt"),
+                 (os.path.join("prof_bf16", "trace_kernel_stats.csv"), "bench_bf16_kernel_stats.csv"),
+                 (os.path.join("corrprof", "t_kernel_stats.csv"), "corr_probe_kernel_stats.csv")):
+    if os.path.exists(os.path.join(G, src)) and os.path.getmtime(os.path.join(G, src)) > float(os.environ.get("SUMMARIZE_NEWER_THAN", "0")):
+        shutil.copy(os.path.join(G, src), os.path.join(P, f"{tag}_{dst}"))
+
 
 def load(path):
     return list(csv.DictReader(open(path))) if os.path.exists(path) else []
