@@ -170,10 +170,27 @@ def warp_features(sd, r2, r3, r4, r5):
     return x
 
 
+class _WTAScale(torch.autograd.Function):
+    """WTA_scale, models/NonlocalNet.py:288-327: forward keeps the row maximum and scales every other affinity by `scale`;
+    backward multiplies the incoming gradient by 1 at the row maximum and by the CONSTANT 1e-4 elsewhere — whatever `scale`
+    is (NonlocalNet.py:320-325) — which is not the derivative of the forward unless scale == 1e-4, and is restated as written."""
+
+    @staticmethod
+    def forward(ctx, f, scale):
+        mx = torch.max(f, -1, keepdim=True)[0]
+        mask = f == mx
+        ctx.save_for_backward(mask)
+        return torch.where(mask, f, f * scale)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (mask,) = ctx.saved_tensors
+        return grad_output * torch.where(mask, torch.ones_like(grad_output), torch.full_like(grad_output, 1e-4)), None
+
+
 def wta_scale(f, scale):
-    """WTA_scale.forward, models/NonlocalNet.py:295-309."""
-    mx = torch.max(f, -1, keepdim=True)[0]
-    return torch.where(f == mx, f, f * scale)
+    """WTA_scale.apply(f, scale), models/NonlocalNet.py:288-327 (forward values as before r05; backward as the reference's)."""
+    return _WTAScale.apply(f, scale)
 
 
 def corr_project(sd, which, feats):

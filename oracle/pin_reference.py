@@ -53,6 +53,7 @@ def import_reference():
         from models.FrameColor import frame_colorization
         import utils.util as rutil
     sys.path.remove(REF)
+    import_reference.WTA_scale = _nl.WTA_scale          # (pinned next to the modules, see main)
     # drop the reference's `models`/`utils` namespace packages so ours can be imported later
     ref_mods = {k: v for k, v in sys.modules.items()
                 if k == "models" or k.startswith("models.") or k == "utils" or k.startswith("utils.")}
@@ -97,6 +98,20 @@ def main(write=True):
     assert set(warp.state_dict().keys()) == set(sd_w.keys())
     assert list(col.state_dict().keys()) == list(sd_c.keys()), "ColorVidNet key order"
     print("state_dict key contract: OK (%d + %d + %d tensors)" % (len(sd_v), len(sd_w), len(sd_c)))
+
+    # WTA_scale (models/NonlocalNet.py:288-327), forward AND backward, against the oracle's restatement: the reference's own
+    # autograd.Function on the same tensors (its backward uses the constant 1e-4 whatever the scale is)
+    gen = torch.Generator().manual_seed(5)
+    for scale in (1e-4, 0.5, 3.0):
+        f = torch.randn(2, 1, 9, 11, generator=gen)
+        up = torch.randn(2, 1, 9, 11, generator=gen)
+        f_ref, f_or = f.clone().requires_grad_(True), f.clone().requires_grad_(True)
+        o_ref, o_or = import_reference.WTA_scale.apply(f_ref, scale), O.wta_scale(f_or, scale)
+        assert torch.equal(o_ref, o_or), ("WTA_scale forward", scale)
+        (o_ref * up).sum().backward()
+        (o_or * up).sum().backward()
+        assert torch.equal(f_ref.grad, f_or.grad), ("WTA_scale backward", scale)
+    print("WTA_scale forward / backward: oracle == reference bit-exact (scales 1e-4, 0.5, 3.0)")
 
     os.makedirs(GOLD, exist_ok=True)
     # ATen's CPU conv/GEMM results depend on the thread count (different blocking -> different summation

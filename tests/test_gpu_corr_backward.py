@@ -55,6 +55,49 @@ def test_fused_correlation_backward_vs_oracle_autograd(h, w, B, T):
     assert (thd2.grad - expect).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("h,w,B,T,scale", [(12, 20, 2, 0.01, 1e-4), (10, 16, 1, 0.01, 0.5), (12, 20, 1, 0.005, 3.0), (27, 48, 1, 0.01, 0.5)])
+def test_fused_correlation_backward_with_wta_scale(h, w, B, T, scale):
+    """WTA_scale (NonlocalNet.py:288-327, `WTA_scale_weight != 1`), differentiated (r05): float64 autograd through
+    oracle.correlate — whose `wta_scale` is the reference's autograd.Function restated, backward constant 1e-4 included,
+    pinned bit-exact against the reference class by oracle/pin_reference.py — against the HIP path: forward through the fused
+    kernel's two-pass WTA instantiation, backward through dvc_corr_softmax_bwd(wta_scale).  The similarity map's gradient is
+    not re-weighted (it is taken before WTA_scale, NonlocalNet.py:481-483): checked on its own."""
+    from dvc_amd import ops
+    from dvc_amd.corr_autograd import fused_correlation
+    from oracle import dvc_oracle as O
+    th, ph, lab, gy, gs = _inputs(B, h, w, 100 * h + w + 7)
+    th64, ph64 = th.double().requires_grad_(True), ph.double().requires_grad_(True)
+    y64, sim64, _ = O.correlate(th64, ph64, lab.double(), T, WTA_scale_weight=scale)
+    ((y64 * gy.double()).sum() + (sim64 * gs.double()).sum()).backward()
+    thd, phd = th.cuda().requires_grad_(True), ph.cuda().requires_grad_(True)
+    blab = ops.avgpool4x4(lab.cuda()).view(B, 3, -1)
+    y, sim, _ = fused_correlation(thd, phd, blab, T, h, w, WTA_scale_weight=scale)
+    ((y * gy.cuda()).sum() + (sim * gs.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    # (forward: the re-weighted softmax is peaked or flat depending on the scale; the bound is the plain case's)
+    assert (y.detach().cpu().double() - y64.detach()).abs().max().item() < 5e-3 * max(1.0, 0.01 / T) * max(1.0, scale)
+    assert (sim.detach().cpu().double() - sim64.detach()).abs().max().item() < 2e-6
+    for name, got, ref in (("theta", thd.grad, th64.grad), ("phi", phd.grad, ph64.grad)):
+        err = (got.cpu().double() - ref).abs().max().item()
+        sc = ref.abs().max().item()
+        print(f"corr backward WTA scale={scale} {h}x{w} B={B} T={T}: d{name} max err {err:.3e} (max |grad| {sc:.3e})")
+        assert err <= 2e-3 * sc, (name, err, sc)
+    # the re-weighting is really differentiated: the plain path's gradient is something else
+    thp, php = th.cuda().requires_grad_(True), ph.cuda().requires_grad_(True)
+    yp, _, _ = fused_correlation(thp, php, blab, T, h, w)
+    (yp * gy.cuda()).sum().backward()
+    thw, phw = th.cuda().requires_grad_(True), ph.cuda().requires_grad_(True)
+    yw, _, _ = fused_correlation(thw, phw, blab, T, h, w, WTA_scale_weight=scale)
+    (yw * gy.cuda()).sum().backward()
+    assert (thp.grad - thw.grad).abs().max().item() > 1e-3 * thp.grad.abs().max().item()
+    # similarity branch alone: unscaled, on the arg-max column only
+    th2, ph2 = th.cuda().requires_grad_(True), ph.cuda().requires_grad_(True)
+    _, sim2, amax2 = fused_correlation(th2, ph2, blab, T, h, w, WTA_scale_weight=scale)
+    sim2.sum().backward()
+    expect = torch.gather(ph.cuda(), 2, amax2.long().unsqueeze(1).expand(B, 256, h * w))
+    assert (th2.grad - expect).abs().max().item() < 1e-5
+
+
 def _oracle_grads_row_chunked(th, ph, lab, gy, gs, T, rows=1024):
     """float64 autograd through the reference's op sequence (NonlocalNet.py:477-500, as oracle.correlate restates it),
     evaluated `rows` query rows at a time so that the P x P matrices (215 MB each in double at 54x96, several of them
