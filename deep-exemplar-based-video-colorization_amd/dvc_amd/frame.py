@@ -168,8 +168,10 @@ class ClipColorizer:
             # moved, it is recomputed from the exemplar (into the same buffers when captured front ends read them) — a new A
             # side must never meet a stale B side
             n_front = sum(1 for net in (self.vgg, self.warp) for _ in net.parameters())
+            # (also when the cache came from another rank, parallel.broadcast_exemplar: every rank holds the exemplar and the
+            # same new weights, and recomputing locally gives what rank 0 would broadcast)
             if (self._weights_fp is not None and fp[:n_front] != self._weights_fp[:n_front] and self.ex_cache is not None
-                    and self.IB_lab is not None and self.features_B is not None):
+                    and self.IB_lab is not None):
                 n = self.n_refs
                 self.set_exemplar(self.IB_lab)
                 self.n_refs = n

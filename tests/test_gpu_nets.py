@@ -821,6 +821,48 @@ def test_graph_replay_notices_reloaded_weights_without_an_eager_call():
         assert not torch.equal(got, ab0)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_reloaded_front_end_weights_refresh_the_cached_exemplar_side(graph):
+    """Advisor (r04): the cached exemplar side (phi, pooled Lab) was computed with the VGG19 / WarpNet weights of its time; after
+    an in-place `load_state_dict` of either, a replayed graph (or an eager call with the cache) used to mix a NEW frame side
+    with the STALE exemplar side.  ClipColorizer._sync_weights now recomputes it from the exemplar when the front end's
+    fingerprint moves — on the per-frame call, the sequential and the pipelined clip."""
+    import contextlib
+    import io
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    from models.ColorVidNet import ColorVidNet
+    from models.NonlocalNet import VGG19_pytorch, WarpNet
+    dev = torch.device("cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        nets = (VGG19_pytorch(), WarpNet(1), ColorVidNet(7))
+    for m, sd in zip(nets, (synth.vgg19_state_dict(0), synth.warpnet_state_dict(0), synth.colorvidnet_state_dict(0))):
+        m.load_state_dict(sd)
+        m.eval().to(dev)
+    H, W = 48, 80
+    frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W).to(dev) for i in range(3)]
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).to(dev)
+    zero = torch.zeros_like(frames[0])
+    cc = ClipColorizer(*nets, temperature=0.01, graph=graph)
+    cc.set_exemplar(IB)
+    ab0, _ = cc.frame(frames[0], zero)
+    for step, (which, seed) in enumerate(((1, 5), (0, 6), (1, 7))):
+        sd = synth.warpnet_state_dict(seed) if which == 1 else synth.vgg19_state_dict(seed)
+        nets[which].load_state_dict(sd)                  # in place: same parameter objects, new versions
+        if step == 0:
+            got = cc.frame(frames[0], zero)[0]
+        elif step == 1:
+            got = cc.clip(frames[:1], lookahead=0)[0]
+        else:
+            got = cc.clip(frames, lookahead=2)[0]
+        torch.cuda.synchronize()
+        fresh = ClipColorizer(*nets, temperature=0.01)   # eager, same modules, exemplar side built with the CURRENT weights
+        fresh.set_exemplar(IB)
+        want = fresh.frame(frames[0], zero)[0]
+        assert torch.equal(got, want), (step, (got - want).abs().max().item())
+        assert not torch.equal(got, ab0)
+
+
 def test_folded_merge_is_bit_identical_in_the_drivers(nets):
     """ops.set_fold_merge: with the correlation's merge folded into pack_color_input (default) and with the separate merge +
     pack launches, frame_colorization (incl. the warped Lab it returns), the sequential and the pipelined clip and the
