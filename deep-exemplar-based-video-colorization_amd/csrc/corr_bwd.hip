@@ -22,11 +22,16 @@
 // (NonlocalNet.py:481-483), so its gradient is not scaled.  wta == 1: the plain path, unchanged.
 __device__ __forceinline__ float wta_apply(float f, float fmax_raw, float wta) { return (wta == 1.f || f == fmax_raw) ? f : f * wta; }
 
-__global__ __launch_bounds__(256) void corr_bwd_rowstat_kernel(const float* __restrict__ F, float T, int P, float wta,
+__global__ __launch_bounds__(256) void corr_bwd_rowstat_kernel(const float* __restrict__ F, float T, int P, int ld, float wta,
                                                                float* __restrict__ m_out, float* __restrict__ l_out,
                                                                float* __restrict__ raw_out) {
     __shared__ float red[4];
     const int row = blockIdx.x;
+    // blockIdx.y = image of the batch (r05): F [B][ld][P], the three row-statistics arrays [B][3][ld]
+    F += (long)blockIdx.y * ld * P;
+    m_out += (long)blockIdx.y * 3 * ld;
+    l_out += (long)blockIdx.y * 3 * ld;
+    raw_out += (long)blockIdx.y * 3 * ld;
     const float* f = F + (long)row * P;
     float raw = -INFINITY;
     if (wta != 1.f) {       // (block-uniform) raw row maximum first: it decides which elements are re-weighted
@@ -71,6 +76,22 @@ __global__ __launch_bounds__(256) void corr_bwd_ds_kernel(const float* __restric
     __shared__ float tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    {   // blockIdx.z = image of the batch (r05): dense batch strides
+        const long bz = blockIdx.z;
+        F += bz * ldt * P;
+        dS += bz * ldt * P;
+        dST += bz * (long)P * ldt;
+        blab += bz * 3 * P;
+        gy += bz * 3 * cs;
+        y += bz * 3 * cs;
+        rowmax += bz * 3 * ldt;
+        lsum += bz * 3 * ldt;
+        rawmax += bz * 3 * ldt;
+        if (gsim) {
+            gsim += bz * cs;
+            amax += bz * cs;
+        }
+    }
     const int j = j0 + tx;
     const bool jok = j < P;
     float b0 = 0.f, b1 = 0.f, b2 = 0.f;
@@ -107,7 +128,7 @@ __global__ __launch_bounds__(256) void corr_bwd_ds_kernel(const float* __restric
 
 extern "C" int dvc_corr_softmax_bwd(const float* f_blk, const float* blab, const float* gy, const float* y,
                                     const float* sim, const float* gsim, const int32_t* argmax, float temperature,
-                                    float wta_scale, int32_t rows, int32_t P, int64_t chan_stride, int32_t ld_t,
+                                    float wta_scale, int32_t batch, int32_t rows, int32_t P, int64_t chan_stride, int32_t ld_t,
                                     float* rowstat_scratch, float* dS, float* dST, dvcStream stream) {
     DVC_REQUIRE(f_blk && blab && gy && y && rowstat_scratch && dS && dST, "dvc_corr_softmax_bwd: null argument");
     (void)sim;
@@ -115,13 +136,13 @@ extern "C" int dvc_corr_softmax_bwd(const float* f_blk, const float* blab, const
     float* lsum_scratch = rowstat_scratch + ld_t;
     float* rawmax = rowstat_scratch + 2 * (size_t)ld_t;
     DVC_REQUIRE(std::isfinite(wta_scale), "dvc_corr_softmax_bwd: bad wta_scale");
-    DVC_REQUIRE(rows > 0 && P > 0 && ld_t >= rows, "dvc_corr_softmax_bwd: bad shape");
+    DVC_REQUIRE(rows > 0 && P > 0 && ld_t >= rows && batch >= 1 && batch <= 65535, "dvc_corr_softmax_bwd: bad shape");
     DVC_REQUIRE(temperature > 0.f && std::isfinite(temperature), "dvc_corr_softmax_bwd: temperature must be > 0");
     DVC_REQUIRE((gsim == nullptr) == (argmax == nullptr), "dvc_corr_softmax_bwd: gsim and argmax come together");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(corr_bwd_rowstat_kernel, dim3(rows), dim3(256), 0, s, f_blk, temperature, P, wta_scale, rowmax, lsum_scratch, rawmax);
+    hipLaunchKernelGGL(corr_bwd_rowstat_kernel, dim3(rows, batch), dim3(256), 0, s, f_blk, temperature, P, ld_t, wta_scale, rowmax, lsum_scratch, rawmax);
     DVC_CHECK_LAUNCH("dvc_corr_softmax_bwd(rowsum)");
-    hipLaunchKernelGGL(corr_bwd_ds_kernel, dim3(cdiv(P, 64), cdiv(ld_t, 64)), dim3(256), 0, s, f_blk, blab, gy, y, rowmax, gsim,
+    hipLaunchKernelGGL(corr_bwd_ds_kernel, dim3(cdiv(P, 64), cdiv(ld_t, 64), batch), dim3(256), 0, s, f_blk, blab, gy, y, rowmax, gsim,
                        argmax, lsum_scratch, rawmax, wta_scale, temperature, rows, P, (long)chan_stride, ld_t, dS, dST);
     DVC_CHECK_LAUNCH("dvc_corr_softmax_bwd(dS)");
     return 0;

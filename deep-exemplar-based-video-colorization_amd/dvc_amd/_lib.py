@@ -92,7 +92,7 @@ SIGNATURES = {
     "dvc_corr_bf16_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
     "dvc_corr_fwd_bf16": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, ctypes.c_float, c_i32, c_i32, c_i32, c_i32,
                                          _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_size_t, _VP]),
-    "dvc_corr_softmax_bwd": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_float, ctypes.c_float, c_i32, c_i32, c_i64, c_i32,
+    "dvc_corr_softmax_bwd": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_float, ctypes.c_float, c_i32, c_i32, c_i32, c_i64, c_i32,
                                             _VP, _VP, _VP, _VP]),
 }
 # diagnostics for tools/ (include/dvc_hip.h, last section): exported by the -DDVC_DEBUG build only

@@ -24,6 +24,7 @@ from . import _lib, ops
 from .ops import _p, _stream
 
 ROW_BLOCK = 2048
+BLOCK_BYTES = 768 << 20     # cap of one [images, R, P] fp32 buffer of the backward pass (three of them live at a time)
 
 
 class _FusedCorrelation(torch.autograd.Function):
@@ -40,6 +41,10 @@ class _FusedCorrelation(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, gsim, _gamax):
+        """r05: the whole batch per launch — the three recompute GEMMs run on the 1x1-convolution engine with PER-IMAGE filters
+        (DvcConvDesc.w_batch_stride, as the contextual losses since r04) and dvc_corr_softmax_bwd takes the batch as a grid
+        dimension: 5 launches per block of R query rows for B images instead of 5 B (+ the staging copies), and grids B times
+        larger.  Images are processed `chunk` at a time so that the three [chunk, R, P] fp32 buffers stay within BLOCK_BYTES."""
         theta, phi, blab, y, sim, amax = ctx.saved_tensors
         T = ctx.temperature
         h, w = ctx.hw
@@ -48,45 +53,52 @@ class _FusedCorrelation(torch.autograd.Function):
         dev = theta.device
         need_sim = gsim is not None and bool((gsim != 0).any())
         gy = torch.zeros_like(y) if gy is None else gy.contiguous().float()
-        gsim_c = gsim.contiguous().float() if need_sim else None
+        gsim_c = gsim.contiguous().float().view(B, P) if need_sim else None
         d_theta = torch.zeros_like(theta)
         d_phi = torch.zeros_like(phi)
         R = min(ROW_BLOCK, (P + 63) // 64 * 64)
-        F = torch.empty((1, R, h, w), device=dev, dtype=torch.float32)
-        dS = torch.empty((1, R, h, w), device=dev, dtype=torch.float32)
-        dST = torch.empty((1, P, R // 32, 32), device=dev, dtype=torch.float32)     # [P][R] as an image of R "pixels"
-        lsum = torch.empty(3 * R, device=dev, dtype=torch.float32)      # row maxima, row sums, raw row maxima of the recomputed block
-        th_blk = torch.zeros((C, R), device=dev, dtype=torch.float32)   # the block's theta columns, K-major ...
-        th_blk_t = torch.zeros((R, C), device=dev, dtype=torch.float32)  # ... and row-major (one pair of buffers for every block)
-        for b in range(B):
-            phi_img = phi[b].view(1, C, h, w)
-            phi_t = phi[b].t().contiguous().view(P, 1, C)            # K-major weights of d theta = phi dS^T
-            dphi_img = d_phi[b].view(1, C, h, w)
-            gyb, yb = gy[b].view(3, P), y[b].view(3, P)
-            simb = sim[b].view(P)
+        chunk = max(1, min(B, BLOCK_BYTES // (4 * R * P)))
+        if (P * C) % 4 or (C * R) % 4:
+            chunk = 1               # (per-image filter slices must be 16-byte aligned)
+        f32 = dict(device=dev, dtype=torch.float32)
+        F = torch.empty((chunk, R, h, w), **f32)
+        dS = torch.empty((chunk, R, h, w), **f32)
+        dST = torch.empty((chunk, P, R // 32, 32), **f32)            # [P][R] per image, as an image of R "pixels"
+        lsum = torch.empty(chunk * 3 * R, **f32)                     # row maxima, row sums, raw row maxima of the recomputed blocks
+        th_blk = torch.zeros((chunk, C, 1, R), **f32)                # the blocks' theta columns, K-major ...
+        th_blk_t = torch.zeros((chunk, R, 1, C), **f32)              # ... and row-major (one pair of buffers for every block)
+        yv, gyv, blv, amv = y.view(B, 3, P), gy.view(B, 3, P), blab.view(B, 3, P), amax.view(B, P)
+        for b0 in range(0, B, chunk):
+            nb = min(chunk, B - b0)
+            sl_b = slice(b0, b0 + nb)
+            phi_img = phi[sl_b].view(nb, C, h, w)
+            phi_t = phi[sl_b].transpose(1, 2).contiguous().view(nb, P, 1, C)       # K-major per-image filters of d theta = phi dS^T
+            dphi_img = d_phi[sl_b].view(nb, C, h, w)
+            Fb, dSb, dSTb, tb, tbt = F[:nb], dS[:nb], dST[:nb], th_blk[:nb], th_blk_t[:nb]
             for i0 in range(0, P, R):
                 rows = min(R, P - i0)
                 if rows < R:
-                    th_blk[:, rows:].zero_()
-                    th_blk_t[rows:].zero_()
-                th_blk[:, :rows].copy_(theta[b][:, i0:i0 + rows])
-                th_blk_t[:rows].copy_(theta[b][:, i0:i0 + rows].t())
-                # F[i, :] = sum_c theta[c, i0 + i] phi[c, :]
-                ops.conv2d(phi_img, th_blk.view(C, 1, R), None, ksize=1, pad=0, out=F)
+                    tb[..., rows:].zero_()
+                    tbt[:, rows:].zero_()
+                tb[:, :, 0, :rows].copy_(theta[sl_b, :, i0:i0 + rows])
+                tbt[:, :rows, 0, :].copy_(theta[sl_b, :, i0:i0 + rows].transpose(1, 2))
+                # F[b, i, :] = sum_c theta[b, c, i0 + i] phi[b, c, :]
+                ops.conv2d(phi_img, tb, None, ksize=1, pad=0, out=Fb)
+                off = 4 * i0
                 rc = lib.dvc_corr_softmax_bwd(
-                    _p(F), _p(blab[b].view(3, P)), ctypes.c_void_p(gyb.data_ptr() + 4 * i0),
-                    ctypes.c_void_p(yb.data_ptr() + 4 * i0), ctypes.c_void_p(simb.data_ptr() + 4 * i0),
-                    ctypes.c_void_p(gsim_c[b].view(P).data_ptr() + 4 * i0) if need_sim else None,
-                    ctypes.c_void_p(amax[b].data_ptr() + 4 * i0) if need_sim else None,
-                    T, ctx.wta, rows, P, P, R, _p(lsum), _p(dS), _p(dST), _stream())
+                    _p(Fb), _p(blv[sl_b]), ctypes.c_void_p(gyv[sl_b].data_ptr() + off), ctypes.c_void_p(yv[sl_b].data_ptr() + off),
+                    ctypes.c_void_p(sim.view(B, P)[sl_b].data_ptr() + off),
+                    ctypes.c_void_p(gsim_c[sl_b].data_ptr() + off) if need_sim else None,
+                    ctypes.c_void_p(amv[sl_b].data_ptr() + off) if need_sim else None,
+                    T, ctx.wta, nb, rows, P, P, R, _p(lsum), _p(dSb), _p(dSTb), _stream())
                 _lib.check(rc, "dvc_corr_softmax_bwd")
                 if rows < R:
-                    dS.view(R, P)[rows:].zero_()
-                # d phi[c, j] += sum_i theta[c, i0 + i] dS[i, j]      (accumulated in place through the skip input)
-                ops.conv2d(dS, th_blk_t.view(R, 1, C), None, ksize=1, pad=0, residual=dphi_img, out=dphi_img)
-                # d theta[c, i0 + i] = sum_j phi[c, j] dS[i, j]
-                dth = ops.conv2d(dST, phi_t, None, ksize=1, pad=0)          # [1, C, R/32, 32]
-                d_theta[b][:, i0:i0 + rows] = dth.view(C, R)[:, :rows]
+                    dSb.view(nb, R, P)[:, rows:].zero_()
+                # d phi[b, c, j] += sum_i theta[b, c, i0 + i] dS[b, i, j]      (accumulated in place through the skip input)
+                ops.conv2d(dSb, tbt, None, ksize=1, pad=0, residual=dphi_img, out=dphi_img)
+                # d theta[b, c, i0 + i] = sum_j phi[b, c, j] dS[b, i, j]
+                dth = ops.conv2d(dSTb, phi_t, None, ksize=1, pad=0)          # [nb, C, R/32, 32]
+                d_theta[sl_b, :, i0:i0 + rows] = dth.view(nb, C, R)[:, :, :rows]
         return d_theta, d_phi, None, None, None, None, None
 
 

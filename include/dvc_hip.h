@@ -401,9 +401,11 @@ int dvc_cx_normalize_bwd(const float* xn, const float* norm, const float* dxn, i
  * saved similarity is not guaranteed to bound it: at T <= 1e-7 a 1e-7 excess would overflow the exponential); `sim` is
  * not read and is kept for the signature.  rowstat_scratch: [3][ld_t] floats (row maxima, row sums, raw row maxima).
  * wta_scale != 1 (r05): WTA_scale of NonlocalNet.py:288-327 ahead of the temperature — f' = (f == max_j f) ? f : f * wta_scale, and its
- * backward's factor (1 at the row maximum, the reference's constant 1e-4 elsewhere); gsim (similarity from f BEFORE it) unscaled. */
+ * backward's factor (1 at the row maximum, the reference's constant 1e-4 elsewhere); gsim (similarity from f BEFORE it) unscaled.
+ * batch (r05): images per call, dense: f_blk / dS [batch][ld_t][P], dST [batch][P][ld_t], blab / gy / y [batch][3][chan_stride]
+ * (gy, y offset to the block's first row), gsim / argmax [batch][chan_stride], rowstat_scratch [batch][3][ld_t]. */
 int dvc_corr_softmax_bwd(const float* f_blk, const float* blab, const float* gy, const float* y, const float* sim,
-                         const float* gsim, const int32_t* argmax, float temperature, float wta_scale, int32_t rows, int32_t P,
+                         const float* gsim, const int32_t* argmax, float temperature, float wta_scale, int32_t batch, int32_t rows, int32_t P,
                          int64_t chan_stride, int32_t ld_t, float* rowstat_scratch, float* dS, float* dST,
                          dvcStream stream);
 
