@@ -326,9 +326,10 @@ class ClipColorizer:
         if (self.graph if graph is None else graph) and not self.batch_plan:      # (batch-planned launches: eager, as in clip())
             return self._frame_graph(IA_lab.detach().contiguous().float(),
                                      dict(IA_last_lab=IA_last_lab.detach().contiguous().float()))
-        ab, nl, _ = frame_colorization(IA_lab, self.IB_lab, IA_last_lab, self.features_B, self.vgg, self.warp,
-                                       self.col, joint_training=False, feature_noise=0,
-                                       temperature=self.temperature, exemplar_cache=self.ex_cache)
+        with ops.batch_plan(self.batch_plan):       # (the plan clip() runs under: the two APIs of one object agree bit for bit)
+            ab, nl, _ = frame_colorization(IA_lab, self.IB_lab, IA_last_lab, self.features_B, self.vgg, self.warp,
+                                           self.col, joint_training=False, feature_noise=0,
+                                           temperature=self.temperature, exemplar_cache=self.ex_cache)
         return ab, nl
 
     def _frame_graph(self, IA_lab, prev):

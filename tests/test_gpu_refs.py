@@ -147,6 +147,16 @@ def test_batched_clips_in_lock_step():
         assert all(tuple(o.shape) == (B, 2, H, W) for o in outs[plan])
         seq = cc.clip(steps, lookahead=0)
         assert all(torch.equal(a, b) for a, b in zip(outs[plan], seq))
+        # the per-frame API of the same object runs under the same plan (advisor, r04: frame() used to replay / launch the
+        # per-image plan while clip() ran the batch plan), with and without the graph flag
+        for graph in (False, True):
+            ccg = ClipColorizer(vgg, warp, col, temperature=T, batch_plan=plan, graph=graph)
+            ccg.set_exemplar(torch.cat(IBs).cuda())
+            last = torch.zeros_like(steps[0])
+            for i in range(2):
+                ab, _ = ccg.frame(steps[i], last)
+                assert torch.equal(ab, outs[plan][i]), (plan, graph, i)
+                last = torch.cat((steps[i][:, 0:1], ab), dim=1)
     worst = 0.0
     for c in range(B):
         one = ClipColorizer(vgg, warp, col, temperature=T)

@@ -5,12 +5,17 @@ geometry rule allows) is further from the fp64 truth than the reference's own CP
 
 1. sensitivity map (no truth needed): all eligible layers on the direct engine = baseline output; then ONE unit at a time on
    Winograd (a unit = a named layer, or a decoder-block pair that runs as one dual launch) and the perturbation field
-   delta_u = ab(unit u on Winograd) - ab(all direct) is measured over a few frames: rms, mean |.|, q999, max.  The
-   perturbations of different layers are independent roundings, so their energies (rms^2) add.
+   delta_u = ab(unit u on Winograd) - ab(all direct) is measured over a few frames: rms, mean |.|, q999, max.  What it showed
+   (profiles/r05_engine_sensitivity.txt): along ColorVidNet the perturbation falls from 8.5e-4 (conv1_1.2) to 2e-5 (conv10_2)
+   and those energies add (the model built on them predicts the measured maps within 2 %); every FRONT-END layer gives the same
+   6e-4 and those do NOT add — at T = 1e-10 the front end reaches ColorVidNet through the arg-max and the similarity map's last
+   bits only, every switch re-draws the same noise — so the greedy maps of step 3 are only a starting point.
 2. price list: what keeping the unit on the direct engine costs, from the per-layer sweep (profiles/rNN_conv_algo_sweep.txt).
 3. greedy selection by energy per microsecond for a list of time budgets.
 4. evaluation against the fp64 truth (oracle on the host CPU) next to CPU fp32, for: direct, speed (geometry rule), each
-   candidate map.  The map that meets `GPU <= CPU fp32` on q999 / mean at the smallest price goes into arch.DIRECT_LAYERS.
+   candidate map (--maps name=layer,...; @front / @cvn / @vgg / @warp / @all expand).  Frames on which an arg-max differs from
+   the truth's are left out on both sides.  The map that meets `GPU <= CPU fp32` at the smallest price goes into
+   arch.DIRECT_LAYERS (profiles/r05_engine_map_eval.txt, r05_engine_map_leave_one_out.txt).
 
 Writes gpurun_out/engine_sensitivity.{txt,json}."""
 import argparse
