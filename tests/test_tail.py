@@ -127,6 +127,30 @@ def test_gpu_tail_matches_oracle(hw, report=print):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hw,num_iter", [((1, 1), 3), ((1, 37), 3), ((5, 1), 2), ((2, 64), 3), ((3, 65), 1), ((64, 129), 3), ((7, 1024), 2),
+                                         ((6, 1100), 2), ((1030, 9), 3), ((40, 60), 8)])
+def test_gpu_fgs_edge_geometries(hw, num_iter):
+    """The scan solver's edges (r05): single rows / columns / pixels, line lengths on and around multiples of the wave size, the
+    longest line it takes (1024), and beyond it in either direction — where dvc_fgs_filter falls back to the thread-per-line
+    sweeps — and the maximum number of iterations; several frames with their own guides in one call.  Against the oracle."""
+    from dvc_amd import tail
+    H, W = hw
+    g = torch.Generator().manual_seed(1000 * H + W)
+    G = 2
+    guide = torch.randint(0, 256, (G, H, W), generator=g, dtype=torch.uint8)
+    guide[1] = (torch.arange(H * W).view(H, W) % 7 * 30).to(torch.uint8)          # (a structured guide next to the noisy one)
+    src = torch.randn(G, 2, H, W, generator=g) * 30
+    got = tail.fgs_filter(guide.cuda(), src.cuda(), num_iter=num_iter).cpu().numpy()
+    for f in range(G):
+        for k in range(2):
+            ref = T.fgs_filter(guide[f].numpy(), src[f, k].numpy(), num_iter=num_iter)
+            err = np.abs(got[f, k] - ref).max()
+            assert err < 1e-3, (hw, num_iter, f, k, err)          # white-noise guide: the worst conditioned systems (cf. frame_tail test)
+    one = tail.fgs_filter(guide[0].cuda(), src[0].cuda(), num_iter=num_iter).cpu().numpy()
+    assert np.array_equal(one, got[0])                            # a frame's result does not depend on the batch it came in
+
+
+@pytest.mark.gpu
 def test_gpu_frame_tail_end_to_end():
     from dvc_amd import tail
     H, W = 54, 96
