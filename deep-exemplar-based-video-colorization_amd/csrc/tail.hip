@@ -112,17 +112,28 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // guide and lambda_t only, not on the image being filtered, so nothing orders them behind the solves; r04 launched 2 x T of these
 // latency chains one after the other, ~25 % of the filter's time).  lambda_t arrives in `lam[t]` (the host's float recurrence).
 struct FgsLambdas { float v[8]; };
-__global__ __launch_bounds__(64) void fgs_coeff_kernel(const float* __restrict__ w, int L, int M, FgsLambdas lam, long iter_stride,
-                                                       float* __restrict__ cp, float* __restrict__ inv, float* __restrict__ ap) {
+// One direction's problem: weights w [guide][L][M] (M lines of length L, thread-per-line layout), outputs at cp / inv / ap.
+struct FgsCoeffDir {
+    const float* w;
+    float *cp, *inv, *ap;
+    int L, M;
+};
+// blockIdx.z = direction * num_iter + iteration: BOTH directions' chains of every iteration in one launch (the row system's
+// 768-long chains and the column system's 432-long ones run side by side: ~55 us instead of 59 + 39, rocprofv3,
+// profiles/r05_tail_kernel_stats*.csv).  A direction with cp == NULL is skipped.
+__global__ __launch_bounds__(64) void fgs_coeff_kernel(FgsCoeffDir d0, FgsCoeffDir d1, int num_iter, FgsLambdas lam, long iter_stride) {
+    const int dir = blockIdx.z / num_iter, it = blockIdx.z - dir * num_iter;
+    const FgsCoeffDir& d = dir ? d1 : d0;
+    const int L = d.L, M = d.M;
     const int m = blockIdx.x * 64 + threadIdx.x;
-    if (m >= M) return;
-    const float lambda = lam.v[blockIdx.z];
+    if (m >= M || !d.cp) return;
+    const float lambda = lam.v[it];
     const long off = (long)blockIdx.y * L * M + m;       // blockIdx.y = guide
-    const float* wp = w + off;
-    float* cpp = cp + off + (long)blockIdx.z * iter_stride;
-    float* ivp = inv + off + (long)blockIdx.z * iter_stride;
+    const float* wp = d.w + off;
+    float* cpp = d.cp + off + (long)it * iter_stride;
+    float* ivp = d.inv + off + (long)it * iter_stride;
     // ap_l = -(a_l inv_l) = (lambda w(l-1,l)) inv_l, the forward sweep's multiplier (ap_0 = 0), for the scan solver; optional
-    float* app = ap ? ap + off + (long)blockIdx.z * iter_stride : nullptr;
+    float* app = d.ap ? d.ap + off + (long)it * iter_stride : nullptr;
     if (app) app[0] = 0.f;
     float a = 0.f;
     float c = L > 1 ? -lambda * wp[0] : 0.f;
@@ -374,10 +385,10 @@ __global__ __launch_bounds__(64) void fgs_solve_kernel(float* __restrict__ f, co
 
 #define FGS_MAX_ITER 8
 extern "C" size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t n_guides, int32_t planes_per_guide, int32_t num_iter) {
-    // per guide: wv, wh_t; (c', 1/m, ap) of every iteration in the coefficient kernel's layout (one direction at a time) and in the
-    // line-major layout of both directions; per plane: the transposed image (+ d' of the thread-per-line fall-back)
+    // per guide: wv, wh_t; (c', 1/m, ap) of every iteration and both directions in the coefficient kernel's layout and in the
+    // line-major layout; per plane: the transposed image (+ d' of the thread-per-line fall-back)
     if (num_iter < 1) num_iter = 1;
-    return sizeof(float) * ((size_t)(2 + 9 * num_iter) * n_guides * H * W + (size_t)2 * n_guides * planes_per_guide * H * W);
+    return sizeof(float) * ((size_t)(2 + 12 * num_iter) * n_guides * H * W + (size_t)2 * n_guides * planes_per_guide * H * W);
 }
 
 extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_guides, int32_t planes_per_guide,
@@ -396,8 +407,9 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
     const size_t IT = (size_t)num_iter * GHW;
     float* wv = reinterpret_cast<float*>(workspace);
     float* wh_t = wv + GHW;
-    float* tmp = wh_t + GHW;        // (c', 1/m, ap) x iterations in the coefficient kernel's [L][M] layout: rows, then columns
-    float* row_lm = tmp + 3 * IT;   // the same, line-major: row system [guide][H][W]
+    float* tmp = wh_t + GHW;        // (c', 1/m, ap) x iterations in the coefficient kernel's [L][M] layout: row system ...
+    float* tmp2 = tmp + 3 * IT;     // ... and column system
+    float* row_lm = tmp2 + 3 * IT;  // the same, line-major: row system [guide][H][W]
     float* col_lm = row_lm + 3 * IT;  //                      column system [guide][W][H]
     float* tr = col_lm + 3 * IT;    // transposed image [plane][W][H]
     float* dp = tr + planes * HW;   // (fall-back only)
@@ -418,19 +430,19 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
     // elimination coefficients of every iteration: one launch per direction (all chains in flight together), then — scan solver —
     // one transposition of the whole set into the line-major layout
     // rows: lines of length W (the row system's [L = W][M = H] layout is the transposed image's)
-    hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(H, 64), n_guides, num_iter), dim3(64), 0, s, wh_t, W, H, lams, (long)GHW, tmp, tmp + IT,
-                       scan ? tmp + 2 * IT : nullptr);
+    {
+        // rows: lines of length W, M = H of them (the row system's [L = W][M = H] layout is the transposed image's); columns: L = H, M = W
+        const FgsCoeffDir rows_d{wh_t, tmp, tmp + IT, scan ? tmp + 2 * IT : nullptr, W, H};
+        const FgsCoeffDir cols_d{wv, tmp2, tmp2 + IT, scan ? tmp2 + 2 * IT : nullptr, H, W};
+        hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(H > W ? H : W, 64), n_guides, 2 * num_iter), dim3(64), 0, s, rows_d, cols_d, num_iter,
+                           lams, (long)GHW);
+        DVC_CHECK_LAUNCH("dvc_fgs_filter(coefficients)");
+    }
     if (scan) {
         hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(H, 32), cdiv(W, 32), ncoef), dim3(256), 0, s, tmp, W, H, row_lm);
-        hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(W, 64), n_guides, num_iter), dim3(64), 0, s, wv, H, W, lams, (long)GHW, tmp, tmp + IT,
-                           tmp + 2 * IT);
-        hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(W, 32), cdiv(H, 32), ncoef), dim3(256), 0, s, tmp, H, W, col_lm);
-    } else {
-        // (fall-back: the thread-per-line solver reads the [L][M] layouts; rows' set stays in tmp, columns' goes to row_lm)
-        hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(W, 64), n_guides, num_iter), dim3(64), 0, s, wv, H, W, lams, (long)GHW, row_lm,
-                           row_lm + IT, (float*)nullptr);
+        hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(W, 32), cdiv(H, 32), ncoef), dim3(256), 0, s, tmp2, H, W, col_lm);
+        DVC_CHECK_LAUNCH("dvc_fgs_filter(coefficient layout)");
     }
-    DVC_CHECK_LAUNCH("dvc_fgs_filter(coefficients)");
     for (int it = 0; it < num_iter; ++it) {
         if (scan) {
             // rows in place on the image; columns on the transposed image
@@ -445,7 +457,7 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
                                planes_per_guide, lams.v[it], dp);
             hipLaunchKernelGGL(transpose_kernel, tgrid_bwd, dim3(256), 0, s, tr, W, H, dst);
             // columns
-            hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(W, 64), planes), dim3(64), 0, s, dst, wv, row_lm + it * GHW, row_lm + IT + it * GHW, H, W,
+            hipLaunchKernelGGL(fgs_solve_kernel, dim3(cdiv(W, 64), planes), dim3(64), 0, s, dst, wv, tmp2 + it * GHW, tmp2 + IT + it * GHW, H, W,
                                planes_per_guide, lams.v[it], dp);
         }
         DVC_CHECK_LAUNCH("dvc_fgs_filter(solve)");
