@@ -504,7 +504,7 @@ def main():
     # exemplar side is memoised behind the call (nets.WarpNet._memo_exemplar_side); with DVC_EXEMPLAR_MEMO=0 it is recomputed per
     # frame as the reference does (timed next to it).
     dropin = None
-    if args.lookahead > 0 and rank == 0 and args.corr == "fp32":
+    if args.lookahead > 0 and rank == 0 and n_gpus == 1 and args.corr == "fp32":     # (single-GPU legs: the N > 1 runs time `value` only)
         from models.FrameColor import frame_colorization
         from utils.util import tensor_lab2rgb, uncenter_l
         vggnet, nonlocal_net, colornet = nets
@@ -700,7 +700,7 @@ def main():
     # `value`, never as `value` — at this configuration that engine is further from the fp64 truth than the reference's own CPU
     # fp32 run (parity.engine_speed_for_comparison), which is why the default keeps arch.DIRECT_LAYERS on the direct engine
     speed_leg = None
-    if rank == 0 and args.lookahead > 0 and ops.conv_algo() == "auto" and ops.direct_layers() and not args.no_speed_leg:
+    if rank == 0 and n_gpus == 1 and args.lookahead > 0 and ops.conv_algo() == "auto" and ops.direct_layers() and not args.no_speed_leg:
         try:
             ops.set_conv_algo("speed")
             cc.clip(frames[:max(Wm, 3)], lookahead=args.lookahead, graph=clip_graph)      # re-capture / autotune under this engine
