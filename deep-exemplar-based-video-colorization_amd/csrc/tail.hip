@@ -67,9 +67,12 @@ extern "C" int dvc_lum_guide_u8(const float* L_centered, int64_t n, uint8_t* gui
 // element); planes x lines threads (2 x 768 / 2 x 432 at 432x768) are all the parallelism the algorithm has.
 __global__ __launch_bounds__(256) void fgs_weights_kernel(const unsigned char* __restrict__ g, int H, int W,
                                                           float inv_sigma, float* __restrict__ wv,
-                                                          float* __restrict__ wh_t) {
-    // wv[y][x]   = w((y,x),(y+1,x))   [H][W]   (last row unused)
-    // wh_t[x][y] = w((y,x),(y,x+1))   [W][H]   (last row unused) — the horizontal weights, transposed
+                                                          float* __restrict__ wh_t, int line_major) {
+    // thread-per-line solver (line_major == 0): every line's elements are M apart
+    //   wv[y][x]   = w((y,x),(y+1,x))   [H][W]   (last row unused)
+    //   wh_t[x][y] = w((y,x),(y,x+1))   [W][H]   (last row unused) — the horizontal weights, transposed
+    // scan solver (line_major == 1, r05): every line contiguous — the first array [H][W] holds the HORIZONTAL weights (row lines),
+    // the second [W][H] the VERTICAL ones transposed (column lines)
     g += (long)blockIdx.y * H * W;
     wv += (long)blockIdx.y * H * W;
     wh_t += (long)blockIdx.y * H * W;
@@ -78,8 +81,9 @@ __global__ __launch_bounds__(256) void fgs_weights_kernel(const unsigned char* _
         const int c = g[i];
         const int dn = y + 1 < H ? abs(c - (int)g[i + W]) : 0;
         const int rt = x + 1 < W ? abs(c - (int)g[i + 1]) : 0;
-        wv[i] = expf(-(float)dn * inv_sigma);
-        wh_t[(long)x * H + y] = expf(-(float)rt * inv_sigma);
+        const float wd = expf(-(float)dn * inv_sigma), wr = expf(-(float)rt * inv_sigma);
+        wv[i] = line_major ? wr : wd;
+        wh_t[(long)x * H + y] = line_major ? wd : wr;
     }
 }
 
@@ -278,6 +282,104 @@ __global__ __launch_bounds__(256) void fgs_solve_scan_kernel(float* __restrict__
     }
 }
 
+// ---- r05: the elimination coefficients without the L-long chain.  c'_l = c_l / (b_l - a_l c'_{l-1}) FORGETS its start: the
+// map is a contraction whose rate is largest for a flat guide (all weights 1), rho(lambda) = x*^2 with x* the fixed point
+// -((1 + 2 lambda) - sqrt(1 + 4 lambda)) / (2 lambda) — 0.865 for the first iteration's lambda_1 = 190 (lambda = 500), 0.75 and
+// 0.56 for the next two.  A wave per line: lane j owns E consecutive elements and first runs the recurrence from 0 over the
+// `warm` elements in front of them (warm = ln(1e-8) / ln(rho): 127, 64, 32 steps: what is left of the arbitrary start is below
+// 1e-8 of c', under the rounding of the fp32 recurrence itself), then over its own with the reference's expressions, writing
+// c', 1/den and ap = -a / den LINE-major: chains of warm + E steps instead of L (139 instead of 768), nlines x 64 lanes instead
+// of nlines threads, and no transposition of the coefficient sets.  (The Moebius-map scan — compose the maps as 2x2 matrices,
+// scan across the lanes — was built first and is too ill-conditioned: the composed maps are nearly constant, the matrix products
+// cancel, c' came out 1.5e-5 off in fp32 (3e-9 in fp64) and the filter 2e-2: profiles/EXPERIMENTS.md.)  lambda so large that
+// warm exceeds FGS_WARM_MAX keeps the thread-per-line chain kernel.
+#define FGS_WARM_MAX 256
+struct FgsWarm { int v[8]; };
+template <int E>
+__global__ __launch_bounds__(256) void fgs_coeff_window_kernel(const float* __restrict__ w, int L, int nlines, FgsLambdas lam,
+                                                              FgsWarm warm, long iter_stride, float* __restrict__ cp,
+                                                              float* __restrict__ inv, float* __restrict__ ap) {
+    constexpr int EP = E | 1;
+    __shared__ float sw[4][64 * E + 1];
+    __shared__ float s0[4][64 * EP], s1[4][64 * EP], s2[4][64 * EP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int line_raw = blockIdx.x * 4 + wv;
+    const bool active = line_raw < nlines;
+    const int line = active ? line_raw : nlines - 1;
+    const float lambda = lam.v[blockIdx.z];
+    const int W = warm.v[blockIdx.z];
+    const long loff = ((long)blockIdx.y * nlines + line) * L;       // blockIdx.y = guide
+    const float* wp = w + loff;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int p = k * 64 + lane;
+        sw[wv][p] = p < L ? wp[p] : 0.f;
+    }
+    __syncthreads();
+    const float* wl = sw[wv];
+    const int l0 = lane * E;
+    // a_l = -lambda w(l-1,l) (0 for l = 0), c_l = -lambda w(l,l+1) (0 for the last element); before the line: x stays 0
+    float x = 0.f;
+    int l = l0 - W;
+    float wprev = (l > 0 && l - 1 < L) ? wl[l - 1] : 0.f;
+    // warm-up: W is wave-uniform and a multiple of 8.  Blocks of 8 steps: the eight LDS reads first (clamped indices, no
+    // branches: as a rolled loop with a conditional read every step waited ~150 cycles for its own ds_read), then the eight
+    // dependent steps.  (hardware reciprocal, 1 ulp: what the warm-up computes is forgotten at the same rate as its start
+    // value — the line's own elements below use the reference's true division)
+    for (int t = 0; t < W; t += 8) {
+        float wk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wk[u] = wl[min(max(l + u, 0), 64 * E - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int li = l + u;
+            const float wc = li >= 0 ? wk[u] : 0.f;                   // (entries beyond the line are zero in LDS)
+            const float a = (li > 0 && li < L) ? -lambda * wprev : 0.f;
+            const float c = (li >= 0 && li + 1 < L) ? -lambda * wc : 0.f;
+            x = c * __builtin_amdgcn_rcpf((1.f - a - c) - a * x);
+            wprev = wc;
+        }
+        l += 8;
+    }
+#pragma unroll
+    for (int k = 0; k < E; ++k, ++l) {
+        const float wc = l < L ? wl[l] : 0.f;
+        const float a = (l > 0 && l < L) ? -lambda * wprev : 0.f;
+        const float c = (l + 1 < L) ? -lambda * wc : 0.f;
+        const float iv = 1.f / ((1.f - a - c) - a * x);
+        x = c * iv;
+        s0[wv][lane * EP + k] = x;
+        s1[wv][lane * EP + k] = iv;
+        s2[wv][lane * EP + k] = -a * iv;
+        wprev = wc;
+    }
+    __syncthreads();
+    if (!active) return;
+    const long ooff = loff + (long)blockIdx.z * iter_stride;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int pi = k * 64 + lane;
+        if (pi < L) {
+            const int qi = (pi / E) * EP + (pi % E);
+            cp[ooff + pi] = s0[wv][qi];
+            inv[ooff + pi] = s1[wv][qi];
+            ap[ooff + pi] = s2[wv][qi];
+        }
+    }
+}
+
+static void fgs_coeff_window(hipStream_t s, const float* w, int L, int nlines, int n_guides, int num_iter, const FgsLambdas& lam,
+                             const FgsWarm& warm, long iter_stride, float* cp, float* inv, float* ap) {
+    const dim3 grid(cdiv(nlines, 4), n_guides, num_iter);
+#define FGS_CWIN(E_) case E_: hipLaunchKernelGGL((fgs_coeff_window_kernel<E_>), grid, dim3(256), 0, s, w, L, nlines, lam, warm, iter_stride, cp, inv, ap); break;
+    switch (cdiv(L, 64)) {
+        FGS_CWIN(1) FGS_CWIN(2) FGS_CWIN(3) FGS_CWIN(4) FGS_CWIN(5) FGS_CWIN(6) FGS_CWIN(7) FGS_CWIN(8)
+        FGS_CWIN(9) FGS_CWIN(10) FGS_CWIN(11) FGS_CWIN(12) FGS_CWIN(13) FGS_CWIN(14) FGS_CWIN(15) FGS_CWIN(16)
+        default: break;
+    }
+#undef FGS_CWIN
+}
+
 static void fgs_solve_scan(hipStream_t s, float* f, const float* ap, const float* inv, const float* cp, int L, int nlines, int planes,
                            int planes_per_guide) {
     const dim3 grid(cdiv(nlines, 4), planes);
@@ -413,36 +515,54 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
     float* col_lm = row_lm + 3 * IT;  //                      column system [guide][W][H]
     float* tr = col_lm + 3 * IT;    // transposed image [plane][W][H]
     float* dp = tr + planes * HW;   // (fall-back only)
+    const bool scan = H <= FGS_SCAN_MAX_L && W <= FGS_SCAN_MAX_L;
+    double lam = 1.5 * (double)lambda * pow(4.0, num_iter - 1) / (pow(4.0, num_iter) - 1.0);
+    FgsLambdas lams;
+    lams.v[0] = (float)lam;
+    for (int it = 1; it < FGS_MAX_ITER; ++it) lams.v[it] = lams.v[it - 1] * lambda_attenuation;      // (the float recurrence of r01-r04)
+    // warm-up lengths of the windowed coefficient kernel: rho^warm <= 1e-8 for the slowest-forgetting (flat) guide
+    FgsWarm warm;
+    int warm_max = 0;
+    for (int it = 0; it < FGS_MAX_ITER; ++it) {
+        const double l = (double)lams.v[it];
+        int wlen = 0;
+        if (l > 0.0) {
+            const double xs = ((1.0 + 2.0 * l) - sqrt(1.0 + 4.0 * l)) / (2.0 * l), rho = xs * xs;
+            wlen = rho < 1e-8 ? 1 : (int)ceil(log(1e-8) / log(rho)) + 1;
+            wlen = (wlen + 7) / 8 * 8;          // (the kernel's warm-up runs in blocks of 8 steps)
+        }
+        warm.v[it] = wlen;
+        if (it < num_iter && wlen > warm_max) warm_max = wlen;
+    }
+    const bool window = scan && warm_max <= FGS_WARM_MAX;
+    // (windowed coefficients: wv = the horizontal weights [H][W], wh_t = the vertical ones transposed [W][H]: every line contiguous)
     hipLaunchKernelGGL(fgs_weights_kernel, dim3(cdiv((int)HW, 1024), n_guides), dim3(256), 0, s, guide, H, W,
-                       1.0f / sigma_color, wv, wh_t);
+                       1.0f / sigma_color, wv, wh_t, window ? 1 : 0);
     DVC_CHECK_LAUNCH("dvc_fgs_filter(weights)");
     if (dst != src) {
         hipError_t e = hipMemcpyAsync(dst, src, sizeof(float) * planes * HW, hipMemcpyDeviceToDevice, s);
         DVC_REQUIRE(e == hipSuccess, "dvc_fgs_filter: copy failed: %s", hipGetErrorString(e));
     }
-    double lam = 1.5 * (double)lambda * pow(4.0, num_iter - 1) / (pow(4.0, num_iter) - 1.0);
-    FgsLambdas lams;
-    lams.v[0] = (float)lam;
-    for (int it = 1; it < FGS_MAX_ITER; ++it) lams.v[it] = lams.v[it - 1] * lambda_attenuation;      // (the float recurrence of r01-r04)
     const dim3 tgrid_fwd(cdiv(W, 32), cdiv(H, 32), planes), tgrid_bwd(cdiv(H, 32), cdiv(W, 32), planes);
-    const bool scan = H <= FGS_SCAN_MAX_L && W <= FGS_SCAN_MAX_L;
-    const int ncoef = 3 * num_iter * n_guides;      // planes of one direction's coefficient set
-    // elimination coefficients of every iteration: one launch per direction (all chains in flight together), then — scan solver —
-    // one transposition of the whole set into the line-major layout
-    // rows: lines of length W (the row system's [L = W][M = H] layout is the transposed image's)
-    {
-        // rows: lines of length W, M = H of them (the row system's [L = W][M = H] layout is the transposed image's); columns: L = H, M = W
+    // elimination coefficients of every iteration, both directions
+    if (window) {
+        // wave-per-line windowed recurrences, written line-major: row system (lines of length W) and column system (length H)
+        fgs_coeff_window(s, wv, W, H, n_guides, num_iter, lams, warm, (long)GHW, row_lm, row_lm + IT, row_lm + 2 * IT);
+        fgs_coeff_window(s, wh_t, H, W, n_guides, num_iter, lams, warm, (long)GHW, col_lm, col_lm + IT, col_lm + 2 * IT);
+    } else {
+        // thread-per-line chains, one launch: rows = lines of length W, M = H of them (the row system's [L = W][M = H] layout is
+        // the transposed image's); columns: L = H, M = W; for the scan solver the sets are then transposed into the line-major layout
         const FgsCoeffDir rows_d{wh_t, tmp, tmp + IT, scan ? tmp + 2 * IT : nullptr, W, H};
         const FgsCoeffDir cols_d{wv, tmp2, tmp2 + IT, scan ? tmp2 + 2 * IT : nullptr, H, W};
         hipLaunchKernelGGL(fgs_coeff_kernel, dim3(cdiv(H > W ? H : W, 64), n_guides, 2 * num_iter), dim3(64), 0, s, rows_d, cols_d, num_iter,
                            lams, (long)GHW);
-        DVC_CHECK_LAUNCH("dvc_fgs_filter(coefficients)");
+        if (scan) {
+            const int ncoef = 3 * num_iter * n_guides;      // planes of one direction's coefficient set
+            hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(H, 32), cdiv(W, 32), ncoef), dim3(256), 0, s, tmp, W, H, row_lm);
+            hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(W, 32), cdiv(H, 32), ncoef), dim3(256), 0, s, tmp2, H, W, col_lm);
+        }
     }
-    if (scan) {
-        hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(H, 32), cdiv(W, 32), ncoef), dim3(256), 0, s, tmp, W, H, row_lm);
-        hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(W, 32), cdiv(H, 32), ncoef), dim3(256), 0, s, tmp2, H, W, col_lm);
-        DVC_CHECK_LAUNCH("dvc_fgs_filter(coefficient layout)");
-    }
+    DVC_CHECK_LAUNCH("dvc_fgs_filter(coefficients)");
     for (int it = 0; it < num_iter; ++it) {
         if (scan) {
             // rows in place on the image; columns on the transposed image

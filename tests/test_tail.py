@@ -148,6 +148,14 @@ def test_gpu_fgs_edge_geometries(hw, num_iter):
             assert err < 1e-3, (hw, num_iter, f, k, err)          # white-noise guide: the worst conditioned systems (cf. frame_tail test)
     one = tail.fgs_filter(guide[0].cuda(), src[0].cuda(), num_iter=num_iter).cpu().numpy()
     assert np.array_equal(one, got[0])                            # a frame's result does not depend on the batch it came in
+    # a lambda so large that the windowed coefficient recurrence would need more than its maximum warm-up (the coefficients then
+    # come from the thread-per-line chains, transposed for the scan solves), and a tiny one (warm-up of one block)
+    for lam in (20000.0, 0.05):
+        got_l = tail.fgs_filter(guide[1].cuda(), src[1].cuda(), lambda_value=lam, num_iter=num_iter).cpu().numpy()
+        for k in range(2):
+            ref = T.fgs_filter(guide[1].numpy(), src[1, k].numpy(), lambda_value=lam, num_iter=num_iter)
+            err = np.abs(got_l[k] - ref).max()
+            assert err < (2e-2 if lam > 1e3 else 1e-3), (hw, num_iter, lam, k, err)      # (lambda = 2e4: systems conditioned ~1e5)
 
 
 @pytest.mark.gpu
