@@ -23,3 +23,6 @@ find gpurun_out -name "*kernel_trace.csv" -size +6M -delete
 timeout 300 python tools/tail_probe.py > gpurun_out/tail_probe.txt 2>&1; tail -9 gpurun_out/tail_probe.txt
 rm -rf gpurun_out/prof_bf16; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bf16 -o trace -- python bench.py --steps 20 --warmup 3 --corr bf16 --no-cpu-baseline --no-speed-leg --refs 0 --clips 0 > gpurun_out/prof_bf16_bench.json 2> gpurun_out/prof_bf16.err; echo "prof bf16 rc=$?"
 find gpurun_out -name "*kernel_trace.csv" -size +6M -delete
+rm -rf gpurun_out/tailprof; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/tailprof -o t -- python tools/tail_trace.py > /dev/null 2>&1; echo "tail trace rc=$?"
+timeout 300 python tools/tail_insitu_probe.py 2>&1 | grep round > gpurun_out/tail_insitu_probe.txt; tail -3 gpurun_out/tail_insitu_probe.txt
+find gpurun_out -name "*kernel_trace.csv" -size +6M -delete
