@@ -331,6 +331,12 @@ class WarpNet(nn.Module):
         object.__setattr__(self, "_exemplar_memo", ([(t, t._version) for t in key_tensors], fp, value))
         return value
 
+    def __getstate__(self):
+        # (pickling / copy.deepcopy of the module: the memo is a cache of tensors, not state)
+        state = dict(self.__dict__)
+        state.pop("_exemplar_memo", None)
+        return state
+
     def exemplar_side(self, B_lab_map, B2, B3, B4, B5, bf16=None):
         """Everything that depends only on the exemplar (recomputed per frame by the reference,
         NonlocalNet.py:452-465,473-476,491-493; cacheable per clip)."""
