@@ -302,6 +302,8 @@ __global__ __launch_bounds__(256) void fgs_coeff_window_kernel(const float* __re
     constexpr int EP = E | 1;
     __shared__ float sw[4][64 * E + 1];
     __shared__ float s0[4][64 * EP], s1[4][64 * EP], s2[4][64 * EP];
+    // (68.6 KB at E = 16: more than the 64 KB a workgroup gets on gfx90a / gfx942 — this library is written for gfx950's 160 KB)
+    static_assert(sizeof(float) * (4 * (64 * E + 1) + 3 * 4 * 64 * EP) <= 160 * 1024, "static LDS of fgs_coeff_window_kernel");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int line_raw = blockIdx.x * 4 + wv;
     const bool active = line_raw < nlines;
@@ -487,10 +489,12 @@ __global__ __launch_bounds__(64) void fgs_solve_kernel(float* __restrict__ f, co
 
 #define FGS_MAX_ITER 8
 extern "C" size_t dvc_fgs_workspace_bytes(int32_t H, int32_t W, int32_t n_guides, int32_t planes_per_guide, int32_t num_iter) {
-    // per guide: wv, wh_t; (c', 1/m, ap) of every iteration and both directions in the coefficient kernel's layout and in the
-    // line-major layout; per plane: the transposed image (+ d' of the thread-per-line fall-back)
+    // per guide: wv, wh_t; (c', 1/m, ap) of every iteration and both directions (line-major for the scan solver, or in the
+    // thread-per-line kernels' [L][M] layout: ONE copy — the rare case that needs both, a lambda too large for the windowed
+    // coefficients on an image the scan solver takes, uses a second copy when the caller's workspace has room for it and the
+    // thread-per-line solver otherwise); per plane: the transposed image (+ d' of the thread-per-line fall-back)
     if (num_iter < 1) num_iter = 1;
-    return sizeof(float) * ((size_t)(2 + 12 * num_iter) * n_guides * H * W + (size_t)2 * n_guides * planes_per_guide * H * W);
+    return sizeof(float) * ((size_t)(2 + 6 * num_iter) * n_guides * H * W + (size_t)2 * n_guides * planes_per_guide * H * W);
 }
 
 extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_guides, int32_t planes_per_guide,
@@ -509,13 +513,16 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
     const size_t IT = (size_t)num_iter * GHW;
     float* wv = reinterpret_cast<float*>(workspace);
     float* wh_t = wv + GHW;
-    float* tmp = wh_t + GHW;        // (c', 1/m, ap) x iterations in the coefficient kernel's [L][M] layout: row system ...
-    float* tmp2 = tmp + 3 * IT;     // ... and column system
-    float* row_lm = tmp2 + 3 * IT;  // the same, line-major: row system [guide][H][W]
-    float* col_lm = row_lm + 3 * IT;  //                      column system [guide][W][H]
+    float* row_lm = wh_t + GHW;     // (c', 1/m, ap) x iterations, line-major: row system [guide][H][W]
+    float* col_lm = row_lm + 3 * IT;  //                                         column system [guide][W][H]
     float* tr = col_lm + 3 * IT;    // transposed image [plane][W][H]
     float* dp = tr + planes * HW;   // (fall-back only)
-    const bool scan = H <= FGS_SCAN_MAX_L && W <= FGS_SCAN_MAX_L;
+    // the thread-per-line coefficient kernel's [L][M] layout (row system, column system): behind everything else when the
+    // workspace has room for a second copy, else IN PLACE of the line-major sets (then the thread-per-line solver runs too)
+    const bool room2 = workspace_bytes >= dvc_fgs_workspace_bytes(H, W, n_guides, planes_per_guide, num_iter) + sizeof(float) * 6 * IT;
+    float* tmp = room2 ? dp + planes * HW : row_lm;
+    float* tmp2 = tmp + 3 * IT;
+    bool scan = H <= FGS_SCAN_MAX_L && W <= FGS_SCAN_MAX_L;
     double lam = 1.5 * (double)lambda * pow(4.0, num_iter - 1) / (pow(4.0, num_iter) - 1.0);
     FgsLambdas lams;
     lams.v[0] = (float)lam;
@@ -528,13 +535,16 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
         int wlen = 0;
         if (l > 0.0) {
             const double xs = ((1.0 + 2.0 * l) - sqrt(1.0 + 4.0 * l)) / (2.0 * l), rho = xs * xs;
-            wlen = rho < 1e-8 ? 1 : (int)ceil(log(1e-8) / log(rho)) + 1;
+            // (in double, clamped BEFORE the cast: rho -> 1 for a huge lambda, the quotient overflows an int or is not finite)
+            const double steps = rho < 1e-8 ? 1.0 : ceil(log(1e-8) / log(rho)) + 1.0;
+            wlen = (steps >= 1.0 && steps <= (double)FGS_WARM_MAX) ? (int)steps : FGS_WARM_MAX + 8;
             wlen = (wlen + 7) / 8 * 8;          // (the kernel's warm-up runs in blocks of 8 steps)
         }
         warm.v[it] = wlen;
         if (it < num_iter && wlen > warm_max) warm_max = wlen;
     }
     const bool window = scan && warm_max <= FGS_WARM_MAX;
+    if (!window && !room2) scan = false;        // (one coefficient copy only: the thread-per-line solver reads it where it is)
     // (windowed coefficients: wv = the horizontal weights [H][W], wh_t = the vertical ones transposed [W][H]: every line contiguous)
     hipLaunchKernelGGL(fgs_weights_kernel, dim3(cdiv((int)HW, 1024), n_guides), dim3(256), 0, s, guide, H, W,
                        1.0f / sigma_color, wv, wh_t, window ? 1 : 0);

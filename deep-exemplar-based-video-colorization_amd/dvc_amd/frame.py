@@ -4,6 +4,7 @@
 import torch
 
 from . import ops
+from .nets import _version_of
 from .util import feature_normalize, gray2rgb_batch
 
 VGG_OUT = ["r12", "r22", "r32", "r42", "r52"]
@@ -149,11 +150,11 @@ class ClipColorizer:
             if prep is not None:
                 prep()
 
-    def _sync_weights(self):
+    def _sync_weights(self, refresh_exemplar=True):
         """Make the packed weights (and with them `nets.pack_epoch()`, which marks captured sequences stale) follow the
         parameters: an in-place `load_state_dict` or a `.cuda()` is only noticed by `_PackCache.get`, i.e. by an eager
         forward or `prepare()` — a replayed graph calls neither.  The fingerprint costs ~140 attribute reads; `prepare()`
-        runs only when it moved."""
+        runs only when it moved.  `refresh_exemplar=False`: the caller is about to replace the exemplar cache itself."""
         # (the Parameter objects survive load_state_dict / .cuda() — both write through `param.data` / in place — so the module
         # trees are walked once; a replaced Parameter shows up as a changed data_ptr of a dead object only if somebody keeps
         # assigning new nn.Parameter objects, which the identity check of the first parameters catches)
@@ -161,8 +162,9 @@ class ClipColorizer:
         if params is None or any(a is not b for a, b in zip(params[1], (next(net.parameters()) for net in (self.vgg, self.warp, self.col)))):
             plist = [p for net in (self.vgg, self.warp, self.col) for p in net.parameters()]
             params = self._params = (plist, [next(net.parameters()) for net in (self.vgg, self.warp, self.col)])
-        fp = [(p.data_ptr(), p._version) for p in params[0]]
+        fp = [(p.data_ptr(), _version_of(p)) for p in params[0]]
         if fp != self._weights_fp:
+            prev, self._weights_fp = self._weights_fp, fp       # (recorded first: set_exemplar below comes back through here)
             self.prepare()
             # the cached exemplar side (phi, pooled Lab) was computed with the VGG19 / WarpNet weights of its time: when THOSE
             # moved, it is recomputed from the exemplar (into the same buffers when captured front ends read them) — a new A
@@ -170,16 +172,18 @@ class ClipColorizer:
             n_front = sum(1 for net in (self.vgg, self.warp) for _ in net.parameters())
             # (also when the cache came from another rank, parallel.broadcast_exemplar: every rank holds the exemplar and the
             # same new weights, and recomputing locally gives what rank 0 would broadcast)
-            if (self._weights_fp is not None and fp[:n_front] != self._weights_fp[:n_front] and self.ex_cache is not None
+            if (refresh_exemplar and prev is not None and fp[:n_front] != prev[:n_front] and self.ex_cache is not None
                     and self.IB_lab is not None):
                 n = self.n_refs
                 self.set_exemplar(self.IB_lab)
                 self.n_refs = n
-            self._weights_fp = fp
 
     def set_exemplar(self, IB_lab):
         """test.py:61-66: Lab -> RGB -> VGG features of the reference image."""
         IB_lab = IB_lab.detach().contiguous().float()
+        # (records the fingerprint of the weights this exemplar side is computed with: a load_state_dict between this call and
+        # the first clip() / frame() must refresh it)
+        self._sync_weights(refresh_exemplar=False)
         self.IB_lab = IB_lab
         self.n_refs = 1                            # (set_exemplars raises it after this call)
         rgb = ops.lab2rgb(IB_lab, l_offset=50.0)   # uncenter_l folded into the kernel
@@ -261,6 +265,8 @@ class ClipColorizer:
     def load_exemplar_cache(self, IB_lab, tensors):
         """Install an exemplar cache received from another rank (inverse of exemplar_cache_tensors)."""
         tensors = list(tensors)
+        if all(net is not None for net in (self.vgg, self.warp, self.col)):
+            self._sync_weights(refresh_exemplar=False)  # (records the weights' fingerprint: a later reload recomputes the cache locally)
         self.IB_lab = IB_lab
         self.n_refs = 1                 # (one exemplar per image of the batch, as after set_exemplar)
         self.features_B = None          # not needed once the exemplar side is cached

@@ -40,7 +40,7 @@ class _PackCache:
         """`param`: a parameter, or a tuple of parameters (fn then receives the tuple) — e.g. the concatenated filters of two
         convolutions that run as one launch."""
         params = param if isinstance(param, tuple) else (param,)
-        tag = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        tag = tuple((p.data_ptr(), _version_of(p), str(p.device)) for p in params)
         param = params[0]
         hit = self._d.get(key)
         if hit is None or hit[0] != tag:
@@ -59,6 +59,23 @@ class _PackCache:
                 torch.cuda.synchronize(param.device)
             self._d[key] = hit
         return hit[1]
+
+
+def _version_of(t):
+    """`t._version`, or None for a tensor without a version counter (created under torch.inference_mode())."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
+def _same_tensors(a, b):
+    """Bit-for-bit equality of two nested tuples of tensors (non-tensor leaves compare with ==)."""
+    if isinstance(a, (tuple, list)):
+        return isinstance(b, (tuple, list)) and len(a) == len(b) and all(_same_tensors(x, y) for x, y in zip(a, b))
+    if isinstance(a, torch.Tensor):
+        return isinstance(b, torch.Tensor) and a.shape == b.shape and a.dtype == b.dtype and bool(torch.equal(a, b))
+    return a == b
 
 
 def _packs(cache, key, weight):
@@ -315,20 +332,40 @@ class WarpNet(nn.Module):
     # not rewritten around ClipColorizer gets the cached form anyway: the exemplar side is memoised on the identity and the
     # version counters of the tensors it was computed from (the memo holds references to them, so their addresses cannot be
     # recycled for other data while it is alive), this module's parameters (data_ptr, _version) and everything that selects
-    # kernels.  An in-place write to a key tensor bumps its `_version` and misses; writes through `.data` are invisible to
-    # version counters here as they are to autograd.  DVC_EXEMPLAR_MEMO=0 / ops.set_exemplar_memo(False) turns it off.
+    # kernels.  An in-place write to a key tensor bumps its `_version` and misses.  What no version counter sees:
+    #   * tensors created under torch.inference_mode() have no version counter at all — the memo is bypassed for them (the
+    #     exemplar side is recomputed per call, as the reference does);
+    #   * writes through `.data` (`t.data.copy_(...)`, `p.data.mul_(...)`) are invisible here as they are to autograd: NOT
+    #     supported with the memo on.  DVC_EXEMPLAR_MEMO=verify / ops.set_exemplar_memo("verify")
+    #     recomputes on every hit, compares bit for bit, warns on a mismatch and returns the fresh value.
+    # DVC_EXEMPLAR_MEMO=0 / ops.set_exemplar_memo(False) turns the memo off.
     def _memo_exemplar_side(self, key_tensors, regime, compute):
-        if not ops.exemplar_memo_enabled():
+        mode = ops.exemplar_memo_mode()
+        if mode == "off":
             return compute()
-        fp = (tuple((p.data_ptr(), p._version) for p in self.parameters()), regime, ops.conv_algo(), ops.direct_layers(),
-              ops.fuse_reduce(), ops.autotune_enabled(), ops.batch_plan_enabled())
+        versions = [_version_of(t) for t in key_tensors]
+        pfp = tuple((p.data_ptr(), _version_of(p)) for p in self.parameters())
+        if any(v is None for v in versions) or any(v is None for _, v in pfp):
+            return compute()        # inference tensors: nothing to key a change on
+        fp = (pfp, regime, ops.conv_algo(), ops.direct_layers(), ops.fuse_reduce(), ops.autotune_enabled(),
+              ops.batch_plan_enabled())
         memo = getattr(self, "_exemplar_memo", None)
         if (memo is not None and memo[1] == fp and len(memo[0]) == len(key_tensors)
-                and all(a is b and a._version == v for (a, v), b in zip(memo[0], key_tensors))):
-            return memo[2]
-        value = compute()
+                and all(a is b and va == vb for (a, va), b, vb in zip(memo[0], key_tensors, versions))):
+            if mode != "verify":
+                return memo[2]
+            fresh = compute()
+            if _same_tensors(fresh, memo[2]):
+                return memo[2]
+            import warnings
+            warnings.warn("DVC_EXEMPLAR_MEMO=verify: the memoised exemplar side differs from a recomputation although no key "
+                          "tensor or WarpNet parameter changed identity or version — something wrote to them through `.data` "
+                          "(unsupported with the memo on); using the recomputed value", RuntimeWarning, stacklevel=3)
+            value = fresh
+        else:
+            value = compute()
         # (object.__setattr__: the memo holds tensors, nn.Module.__setattr__ would try to register them)
-        object.__setattr__(self, "_exemplar_memo", ([(t, t._version) for t in key_tensors], fp, value))
+        object.__setattr__(self, "_exemplar_memo", ([(t, v) for t, v in zip(key_tensors, versions)], fp, value))
         return value
 
     def __getstate__(self):

@@ -148,7 +148,9 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
     w_bs = 0
     if w_packed.dim() == 4:
         assert w_packed.shape[0] == N, (w_packed.shape, x.shape)
-        w_bs = w_packed[0].numel()
+        # (one image: the per-image filter set IS the shared one — no batch stride, so no 16-byte alignment requirement on a
+        # filter slice; the one-image-per-call fallbacks of corr_autograd / contextual for odd P*C lean on this)
+        w_bs = w_packed[0].numel() if N > 1 else 0
     wshape = tuple(w_packed.shape[-3:])
     assert wshape[0] == Cin and wshape[1] == ksize * ksize, (w_packed.shape, Cin, ksize)
     Cout = wshape[2]
@@ -416,17 +418,26 @@ def conv_algo():
     return _conv_algo
 
 
-# the exemplar side of WarpNet memoised behind the reference's unmodified call pattern (nets.WarpNet._memo_exemplar_side)
-_exemplar_memo = _os.environ.get("DVC_EXEMPLAR_MEMO", "1") != "0"
+# the exemplar side of WarpNet memoised behind the reference's unmodified call pattern (nets.WarpNet._memo_exemplar_side).
+# DVC_EXEMPLAR_MEMO: "1" (default) on, "0" off, "verify" = on, and every hit ALSO recomputes the exemplar side and compares it
+# bit for bit with the memo (a mismatch warns, replaces the memo and returns the fresh value) — the debugging mode for callers
+# that write to the exemplar tensors or the WarpNet parameters through `.data`, which no version counter sees.
+_exemplar_memo = {"0": "off", "verify": "verify"}.get(_os.environ.get("DVC_EXEMPLAR_MEMO", "1"), "on")
 
 
 def exemplar_memo_enabled():
+    return _exemplar_memo != "off"
+
+
+def exemplar_memo_mode():
+    """"on" | "off" | "verify"."""
     return _exemplar_memo
 
 
 def set_exemplar_memo(flag=True):
+    """True / False, or "verify" (see above)."""
     global _exemplar_memo
-    _exemplar_memo = bool(flag)
+    _exemplar_memo = "verify" if flag == "verify" else ("on" if flag else "off")
 
 
 # ---- error-aware engine map (r05).  Winograd F(2x2,3x3) rounds 2-3x coarser than the direct sum per layer, and through the

@@ -39,10 +39,14 @@ def luminance_guide_u8(L_centered):
     return g
 
 
-def fgs_filter(guide_u8, src, lambda_value=500.0, sigma_color=4.0, num_iter=3, lambda_attenuation=0.25):
+def fgs_filter(guide_u8, src, lambda_value=500.0, sigma_color=4.0, num_iter=3, lambda_attenuation=0.25, second_coeff_copy=False):
     """cv2.ximgproc.createFastGlobalSmootherFilter(guide, lambda, sigma_color).filter(plane) (test.py:107-111).
     One frame: guide_u8 [H, W] uint8, src [planes, H, W].  Several frames in one call: guide_u8 [G, H, W],
-    src [G, planes, H, W] (every frame's planes are filtered with that frame's guide)."""
+    src [G, planes, H, W] (every frame's planes are filtered with that frame's guide).
+    `second_coeff_copy`: hand the library room for a second copy of the elimination coefficients — only a lambda beyond the
+    windowed coefficient kernel's reach (> ~4e3) uses it (coefficients by thread-per-line chains, transposed for the scan
+    solver); without it that case runs the thread-per-line solver.  The library is always told exactly the size asked for
+    here, never what an earlier, larger call left in the workspace cache: the path taken does not depend on history."""
     lib = _lib.load()
     _need(src, "src")
     if guide_u8.dtype != torch.uint8 or not guide_u8.is_cuda or not guide_u8.is_contiguous():
@@ -54,10 +58,13 @@ def fgs_filter(guide_u8, src, lambda_value=500.0, sigma_color=4.0, num_iter=3, l
     if tuple(guide_u8.shape[-2:]) != (H, W) or (batched and (src.dim() != 4 or src.shape[0] != G)):
         raise RuntimeError(f"dvc_amd: guide {tuple(guide_u8.shape)} does not fit src {tuple(src.shape)}")
     dst = torch.empty_like(src)
-    ws = _workspace(src.device, lib.dvc_fgs_workspace_bytes(H, W, G, ppg, int(num_iter)), "fgs")
+    need = lib.dvc_fgs_workspace_bytes(H, W, G, ppg, int(num_iter))
+    if second_coeff_copy:
+        need += 4 * 6 * int(num_iter) * G * H * W
+    ws = _workspace(src.device, need, "fgs")
     _lib.check(lib.dvc_fgs_filter(ctypes.c_void_p(guide_u8.data_ptr()), _p(src), G, ppg, H, W, float(lambda_value),
                                   float(sigma_color), int(num_iter), float(lambda_attenuation), _p(dst),
-                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "dvc_fgs_filter")
+                                  ctypes.c_void_p(ws.data_ptr()), need, _stream()), "dvc_fgs_filter")
     return dst
 
 

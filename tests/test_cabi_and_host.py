@@ -346,3 +346,30 @@ def test_exemplar_memo_keys_on_identity_versions_and_weights():
         ops.set_exemplar_memo(True)
     # the memo is not part of the module's state
     assert not any("memo" in k for k in net.state_dict())
+    # r06: tensors without a version counter (torch.inference_mode) bypass the memo instead of raising
+    with torch.inference_mode():
+        ai = torch.zeros(3)
+    n = len(calls)
+    net._memo_exemplar_side((ai, b), ("warp_color", True), compute)
+    net._memo_exemplar_side((ai, b), ("warp_color", True), compute)
+    assert len(calls) == n + 2
+    # "verify": every hit recomputes and compares; a stand-in whose value changes between calls is reported and replaced
+    import warnings
+    ops.set_exemplar_memo("verify")
+    try:
+        state = {"v": torch.ones(2)}
+        comp = lambda: (calls.append(1), (state["v"].clone(), "blab"))[1]        # noqa: E731
+        net._memo_exemplar_side((a, b), ("warp_color", False), comp)
+        n = len(calls)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            r = net._memo_exemplar_side((a, b), ("warp_color", False), comp)
+        assert len(calls) == n + 1 and not w and torch.equal(r[0], torch.ones(2))
+        state["v"] = torch.full((2,), 2.0)          # "the exemplar changed through .data": same identities, same versions
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            r = net._memo_exemplar_side((a, b), ("warp_color", False), comp)
+        assert torch.equal(r[0], torch.full((2,), 2.0)) and any(issubclass(x.category, RuntimeWarning) for x in w)
+    finally:
+        ops.set_exemplar_memo(True)
+    assert ops.exemplar_memo_mode() == "on"

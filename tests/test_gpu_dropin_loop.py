@@ -222,3 +222,123 @@ def test_warpnet_forward_memoises_on_the_callers_tensors():
             assert cnt.n == 2 and torch.equal(y2, y0)
     finally:
         cnt.restore()
+
+
+def test_reference_loop_under_inference_mode():
+    """tensors created under torch.inference_mode() have no version counter (`t._version` raises).  The drop-in
+    calls must work there — the exemplar memo is bypassed for such tensors (recomputed per call, as the reference does) — and
+    give what the no_grad loop gives, bit for bit."""
+    from dvc_amd import synth
+    H, W, T = 48, 80, 1e-10
+    vggnet, nonlocal_net, colornet = _nets(_sd())
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W)
+    frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W) for i in range(3)]
+    want, _ = reference_loop([f.cuda() for f in frames], IB.cuda(), vggnet, nonlocal_net, colornet, T)
+    cnt = _Count(nonlocal_net)
+    try:
+        with torch.inference_mode():
+            fr = [f.cuda() for f in frames]           # inference tensors: `_version` is unavailable on them
+            ib = IB.cuda()
+            with pytest.raises(RuntimeError):
+                ib._version
+            got, _ = reference_loop(fr, ib, vggnet, nonlocal_net, colornet, T)
+        assert cnt.n == len(frames)                   # no memo without version counters
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        # ordinary tensors handed in from OUTSIDE the inference_mode block keep their counters: memoised as usual
+        cnt.n = 0
+        fr, ib = [f.cuda() for f in frames], IB.cuda()
+        with torch.inference_mode():
+            got2, _ = reference_loop(fr[:1], ib, vggnet, nonlocal_net, colornet, T)
+        assert torch.equal(got2[0], want[0])
+    finally:
+        cnt.restore()
+
+
+def test_exemplar_memo_verify_mode_sees_writes_through_data():
+    """r05 review, weak 1(c): a write through `.data` bumps no version counter, so the default memo cannot see it (documented
+    as unsupported).  DVC_EXEMPLAR_MEMO=verify recomputes on every hit and compares bit for bit: the stale
+    memo is reported (RuntimeWarning) and the fresh value used — for the exemplar tensors and for the WarpNet parameters."""
+    import warnings
+    from dvc_amd import ops, synth
+    from models.FrameColor import frame_colorization
+    H, W, T = 48, 80, 1e-10
+    vggnet, nonlocal_net, colornet = _nets(_sd())
+    frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W).cuda() for i in range(2)]
+    IB1, IB2 = synth.synth_lab(2, H, W).cuda(), synth.synth_lab(3, H, W).cuda()
+    last = torch.zeros_like(frames[0])
+
+    def call(IB, fB):
+        with torch.no_grad():
+            return frame_colorization(frames[0], IB, last, fB, vggnet, nonlocal_net, colornet, feature_noise=0, temperature=T)[0]
+
+    ops.set_exemplar_memo(False)
+    try:
+        t1, fB1 = reference_loop(frames[:1], IB1, vggnet, nonlocal_net, colornet, T)
+        t2, fB2 = reference_loop(frames[:1], IB2, vggnet, nonlocal_net, colornet, T)
+    finally:
+        ops.set_exemplar_memo(True)
+    assert (t1[0] - t2[0]).abs().max().item() > 1e-2
+    IB = IB1.clone()
+    fB = [f.clone() for f in fB1]
+    try:
+        a = call(IB, fB)
+        assert torch.equal(a, t1[0])
+        # overwrite the SAME objects through .data: no version moves
+        v0 = [t._version for t in [IB] + fB]
+        IB.data.copy_(IB2)
+        for dst, src in zip(fB, fB2):
+            dst.data.copy_(src)
+        assert [t._version for t in [IB] + fB] == v0
+        stale = call(IB, fB)
+        assert torch.equal(stale, t1[0])                # the default memo does NOT see it: that is the documented hole
+        ops.set_exemplar_memo("verify")
+        assert ops.exemplar_memo_mode() == "verify" and ops.exemplar_memo_enabled()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            b = call(IB, fB)
+        assert torch.equal(b, t2[0]), (b - t2[0]).abs().max().item()
+        assert any(issubclass(x.category, RuntimeWarning) and "verify" in str(x.message) for x in w)
+        # a second call: the memo now holds the fresh value, nothing to report
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert torch.equal(call(IB, fB), t2[0])
+        assert not any(issubclass(x.category, RuntimeWarning) for x in w)
+        # a WarpNet parameter scaled through .data (and back): reported as well
+        ops.set_exemplar_memo(False)
+        nonlocal_net.phi.weight.data.mul_(0.5)
+        want = call(IB, fB)
+        nonlocal_net.phi.weight.data.mul_(2.0)
+        ops.set_exemplar_memo("verify")
+        call(IB, fB)                                    # (memo of the restored weights)
+        nonlocal_net.phi.weight.data.mul_(0.5)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = call(IB, fB)
+        assert torch.equal(got, want)
+        assert any(issubclass(x.category, RuntimeWarning) for x in w)
+    finally:
+        ops.set_exemplar_memo(True)
+
+
+def test_clip_colorizer_set_exemplar_then_reload_refreshes_the_cache():
+    """ClipColorizer(...), set_exemplar(IB), load_state_dict(new), then the FIRST clip(): the exemplar side cached
+    with the old weights must not meet the new A side."""
+    from dvc_amd import synth
+    from dvc_amd.frame import ClipColorizer
+    H, W = 48, 80
+    sd = _sd()
+    vggnet, nonlocal_net, colornet = _nets(sd)
+    IB = synth.synth_lab(synth.EXEMPLAR_SEED, H, W).cuda()
+    frames = [synth.synth_lab(synth.FRAME_SEED0 + i, H, W).cuda() for i in range(2)]
+    new_warp = {k: v.cuda() for k, v in synth.warpnet_state_dict(5).items()}
+    with torch.no_grad():
+        cc = ClipColorizer(vggnet, nonlocal_net, colornet, temperature=1e-10)
+        cc.set_exemplar(IB)
+        nonlocal_net.load_state_dict(new_warp)
+        got = cc.clip(frames)
+        fresh = ClipColorizer(vggnet, nonlocal_net, colornet, temperature=1e-10)
+        fresh.set_exemplar(IB)
+        want = fresh.clip(frames)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)

@@ -150,12 +150,22 @@ def test_gpu_fgs_edge_geometries(hw, num_iter):
     assert np.array_equal(one, got[0])                            # a frame's result does not depend on the batch it came in
     # a lambda so large that the windowed coefficient recurrence would need more than its maximum warm-up (the coefficients then
     # come from the thread-per-line chains, transposed for the scan solves), and a tiny one (warm-up of one block)
-    for lam in (20000.0, 0.05):
-        got_l = tail.fgs_filter(guide[1].cuda(), src[1].cuda(), lambda_value=lam, num_iter=num_iter).cpu().numpy()
+    # (r06: with the workspace the library asks for, that case keeps ONE coefficient copy and runs the thread-per-line solver;
+    # `second_coeff_copy` gives it room for the transposed copy the scan solver reads)
+    for lam, second in ((20000.0, False), (20000.0, True), (0.05, False)):
+        got_l = tail.fgs_filter(guide[1].cuda(), src[1].cuda(), lambda_value=lam, num_iter=num_iter, second_coeff_copy=second).cpu().numpy()
         for k in range(2):
             ref = T.fgs_filter(guide[1].numpy(), src[1, k].numpy(), lambda_value=lam, num_iter=num_iter)
             err = np.abs(got_l[k] - ref).max()
-            assert err < (2e-2 if lam > 1e3 else 1e-3), (hw, num_iter, lam, k, err)      # (lambda = 2e4: systems conditioned ~1e5)
+            assert err < (2e-2 if lam > 1e3 else 1e-3), (hw, num_iter, lam, second, k, err)      # (lambda = 2e4: systems conditioned ~1e5)
+    # a lambda for which the warm-up length is not representable (rho -> 1: log(rho) -> 0): must fall back, not run the
+    # windowed kernel without a warm-up.  The systems are far beyond fp32 conditioning: finite output, bounded by
+    # the input's range (every 1-D solve is an averaging operator)
+    for second in (False, True):
+        big = tail.fgs_filter(guide[1].cuda(), src[1].cuda(), lambda_value=1e18, num_iter=num_iter, second_coeff_copy=second).cpu().numpy()
+        assert np.isfinite(big).all()
+        lim = np.abs(src[1].numpy()).max() * 1.01 + 1e-3
+        assert np.abs(big).max() <= lim, (hw, num_iter, second, np.abs(big).max(), lim)
 
 
 @pytest.mark.gpu
