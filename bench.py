@@ -291,6 +291,72 @@ def relaunch_under_torchrun(n):
     return subprocess.call(cmd, env=env)
 
 
+def other_config_leg(nets, device, h, w, corr, K, reps, lookahead, use_graph):
+    """One of BASELINE.json's other single-GPU configurations, timed inside this run (r05 review: configs[3] and configs[4] only
+    had builder-run lines): a K-frame clip at h x w with the `corr` correlation through the same pipelined driver as `value`,
+    `reps` times, median; plus the configuration's correlation launch set on the clip's own operands.  Warm-up (autotune of
+    the new shapes, graph capture, stream pools) is untimed.  Short by design — the headline's repeats / p10 / p90 machinery
+    stays with the headline; the stand-alone lines under profiles/ (bench.py --hw 432x768 / --corr bf16) are the long form."""
+    from dvc_amd import ops, synth
+    from dvc_amd.frame import VGG_OUT, ClipColorizer
+    from dvc_amd.util import feature_normalize, gray2rgb_batch
+    vgg, warp, _ = nets
+    keep = warp.corr_precision
+    warp.corr_precision = corr
+    try:
+        cc = ClipColorizer(*nets, temperature=1e-10, graph=use_graph)
+        cc.set_exemplar(synth.synth_lab(synth.EXEMPLAR_SEED, h, w).to(device))
+        Wm = 3
+        frames = [synth.synth_lab(synth.FRAME_SEED0 + i, h, w).to(device) for i in range(K + Wm)]
+        for _ in range(2):
+            cc.clip(frames[:Wm], lookahead=lookahead)
+        last = cc.last_lab
+
+        def run():
+            cc.clip(frames[Wm:], last=last, lookahead=lookahead)
+            return cc.last_lab
+        run()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = run()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        assert torch.isfinite(out).all(), "non-finite output"
+        t = sorted(ts)[len(ts) // 2]
+        # the configuration's correlation stage on the clip's own operands (HIP events on the launch stream)
+        p = (h // 4) * (w // 4)
+        flops = 2.0 * p * p * C + 2.0 * p * p * 3
+        fA = vgg(gray2rgb_batch(frames[Wm][:, 0:1]), VGG_OUT)
+        fe = warp.features(*[feature_normalize(x) for x in fA[1:]])
+        bf16 = corr == "bf16"
+        th = warp.project("theta", fe, bf16=bf16)
+        ph, bl4 = cc.ex_cache
+        bl = bl4.view(1, 3, -1)
+        if bf16:
+            launch = lambda: ops.corr_fwd_bf16(th, ph, bl, 1e-10, h // 4, w // 4)       # noqa: E731
+        else:
+            launch = lambda: ops.corr_fwd(th, ph, bl, 1e-10, h // 4, w // 4, defer_merge=ops.fold_merge())   # noqa: E731
+        n_warm, n_rep = (100, 50) if p <= 6000 else (10, 10)
+        for _ in range(n_warm):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_rep):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        t_corr = e0.elapsed_time(e1) * 1e-3 / n_rep
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+        return {"frames_per_s": round(K / t, 3), "ms_per_step": round(t / K * 1e3, 4), "steps": K, "repeats": reps,
+                "ms_per_step_min_max": [round(min(ts) / K * 1e3, 4), round(max(ts) / K * 1e3, 4)],
+                "corr_launch_us": round(t_corr * 1e6, 2), "corr_frac": round(flops / t_corr / 1e12 / peak, 4),
+                "corr_peak_tflops": peak, "corr_gflop": round(flops / 1e9, 2)}
+    finally:
+        warp.corr_precision = keep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,6 +390,9 @@ def main():
                          "test.py:169-181); 0 skips the leg")
     ap.add_argument("--corr", choices=["fp32", "bf16"], default="fp32",
                     help="bf16 = BASELINE configs[4]: bf16 MFMA candidate filter + exact fp32 re-scoring")
+    ap.add_argument("--other-steps", type=int, default=20,
+                    help="steps of the config.other_configs legs (BASELINE configs[3] 432x768 and configs[4] bf16 correlation, timed "
+                         "in the default single-GPU 216x384 fp32 run, 3 repeats each); 0 skips them")
     ap.add_argument("--no-exemplar-cache", action="store_true",
                     help="recompute the exemplar side of WarpNet every frame, as the reference does")
     args = ap.parse_args()
@@ -725,6 +794,26 @@ def main():
             parity = parity_block(cc, sd, device)
             log(f"[bench] parity vs fp64: GPU {parity['gpu_vs_fp64']}  CPU fp32 {parity['cpu32_vs_fp64']}")
 
+    other = None
+    if (rank == 0 and n_gpus == 1 and (H, W) == (216, 384) and args.corr == "fp32" and args.lookahead > 0 and args.other_steps > 0
+            and not args.no_exemplar_cache):
+        t_o = time.perf_counter()
+        other = {}
+        for name, (h_, w_, corr_) in (("432x768", (432, 768, "fp32")), ("bf16", (216, 384, "bf16"))):
+            try:
+                other[name] = other_config_leg(nets, device, h_, w_, corr_, args.other_steps, 3, args.lookahead, use_graph)
+            except Exception as e:      # noqa: BLE001  (a leg that fails must not take the headline line with it)
+                other[name] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"[bench] other config {name}: {other[name]}")
+        other["432x768"]["workload"] = ("BASELINE configs[3]: 1x3x432x768 frame + one exemplar per step (P = 20736 correlation "
+                                        "positions), same driver and engine choice as `value`, fp32")
+        other["bf16"]["workload"] = ("BASELINE configs[4], 1 GPU: 216x384, correlation = bf16 MFMA candidate filter + exact fp32 "
+                                     "re-scoring (results identical to the fp32 kernel's at T <= 1e-4; an exactness-preserving "
+                                     "filter, no bf16-rate claim: corr_frac is against the dense bf16 peak)")
+        other["note"] = (f"{args.other_steps} steps x 3 repeats each (median), warm-up with autotune / capture untimed; "
+                         f"{time.perf_counter() - t_o:.1f} s of this run; corr_launch_us / corr_frac: the configuration's correlation "
+                         "launch set on the clip's own operands, HIP events")
+
     if rank == 0:
         line = {
             "metric": f"colorized frames/sec/GPU at {H}x{W}; correlation HBM GB/s vs roofline",
@@ -774,6 +863,7 @@ def main():
                                         "recomputing it; tests/test_gpu_dropin_loop.py)"),
                        "eager_launch_clip_driver_frames_per_s": None if eager_fps is None else round(eager_fps, 3),
                        "batched_clips": batched,
+                       "other_configs": other,
                        "multi_reference": None if multi is None else dict(
                            multi, speedup_vs_one_pass_per_reference=round(multi["frame_colorizations_per_s"] / (fps / n_gpus), 3))},
             "roofline": roof,

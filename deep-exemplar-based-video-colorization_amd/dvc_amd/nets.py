@@ -61,6 +61,24 @@ class _PackCache:
         return hit[1]
 
 
+def invalidate_weight_caches(*modules):
+    """Forget every packed filter (and the exemplar memo) of the given modules: the next forward repacks from the current
+    parameter values.  Needed only after writing parameters THROUGH `.data` (`p.data.copy_(...)`), which moves no version
+    counter; `load_state_dict`, `.cuda()` and in-place operations on the Parameter itself are noticed without it.  Captured
+    launch sequences re-capture (pack_epoch moves); a ClipColorizer's cached exemplar side does not know: call its
+    `set_exemplar` again when VGG19 / WarpNet weights were rewritten this way."""
+    global _pack_epoch
+    for m in modules:
+        cache = getattr(m, "_cache", None)
+        if isinstance(cache, _PackCache):
+            if any(p.is_cuda for p in m.parameters()):
+                torch.cuda.synchronize()
+            cache._d.clear()
+        if getattr(m, "_exemplar_memo", None) is not None:
+            object.__setattr__(m, "_exemplar_memo", None)
+    _pack_epoch += 1
+
+
 def _version_of(t):
     """`t._version`, or None for a tensor without a version counter (created under torch.inference_mode())."""
     try:

@@ -158,14 +158,23 @@ def test_gpu_fgs_edge_geometries(hw, num_iter):
             ref = T.fgs_filter(guide[1].numpy(), src[1, k].numpy(), lambda_value=lam, num_iter=num_iter)
             err = np.abs(got_l[k] - ref).max()
             assert err < (2e-2 if lam > 1e3 else 1e-3), (hw, num_iter, lam, second, k, err)      # (lambda = 2e4: systems conditioned ~1e5)
-    # a lambda for which the warm-up length is not representable (rho -> 1: log(rho) -> 0): must fall back, not run the
-    # windowed kernel without a warm-up.  The systems are far beyond fp32 conditioning: finite output, bounded by
-    # the input's range (every 1-D solve is an averaging operator)
+    # lambda = 1e7: the largest decade at which the fp32 recurrences of the algorithm are still finite (the oracle — and the
+    # reference's fp32 filter — divide by zero from ~1e8 on); far beyond the windowed kernel's warm-up budget.  At 1e18 the
+    # warm-up length is not even representable (rho -> 1, log(rho) -> 0: ADVICE r05): the library must take the fall-back,
+    # i.e. do what the oracle does (NaN / inf included), not run the windowed kernel without a warm-up
     for second in (False, True):
+        got_l = tail.fgs_filter(guide[1].cuda(), src[1].cuda(), lambda_value=1e7, num_iter=num_iter, second_coeff_copy=second).cpu().numpy()
+        with np.errstate(all="ignore"):
+            ref = np.stack([T.fgs_filter(guide[1].numpy(), src[1, k].numpy(), lambda_value=1e7, num_iter=num_iter) for k in range(2)])
+        if np.isfinite(ref).all():
+            scale = np.abs(src[1].numpy()).max()
+            assert np.isfinite(got_l).all() and np.abs(got_l - ref).max() < 0.2 * scale, (hw, num_iter, second, np.abs(got_l - ref).max())
         big = tail.fgs_filter(guide[1].cuda(), src[1].cuda(), lambda_value=1e18, num_iter=num_iter, second_coeff_copy=second).cpu().numpy()
-        assert np.isfinite(big).all()
-        lim = np.abs(src[1].numpy()).max() * 1.01 + 1e-3
-        assert np.abs(big).max() <= lim, (hw, num_iter, second, np.abs(big).max(), lim)
+        with np.errstate(all="ignore"):
+            ref = np.stack([T.fgs_filter(guide[1].numpy(), src[1, k].numpy(), lambda_value=1e18, num_iter=num_iter) for k in range(2)])
+        assert big.shape == ref.shape
+        if np.isfinite(ref).all():
+            assert np.isfinite(big).all()
 
 
 @pytest.mark.gpu
