@@ -115,7 +115,9 @@ __device__ __forceinline__ int map_virtual(int v, int V, int pad_mode) {
     return (v >= 0 && v < V) ? v : -1;  // far outside only happens for discarded partial-tile outputs
 }
 
-__device__ __forceinline__ int stored_offset(const ConvKArgs& a, int vy, int vx) {
+// (A = ConvKArgs in whatever address space the caller holds it: generic, or the kernel-argument segment)
+template <class A>
+__device__ __forceinline__ int stored_offset(const A& a, int vy, int vx) {
     int sy = map_virtual(vy, a.VH, a.pad_mode);
     int sx = map_virtual(vx, a.VW, a.pad_mode);
     if (sy < 0 || sx < 0) return -1;

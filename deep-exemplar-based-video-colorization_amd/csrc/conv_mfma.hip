@@ -570,9 +570,12 @@ extern "C" int dvc_conv2d_winograd_split(const DvcConvDesc* d, size_t workspace_
 
 // d2 / x2 != NULL: the two-input form (dvc_conv2d_winograd_dual) — `d` then carries the TOTAL channel count and the first
 // input's geometry, `d2` the second input's (Cin, H, W, in_up, in_sub).
-static int wino_run(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x, const float* x2, const float* u_packed,
-                    const float* bias, const float* act_slope_ptr, const float* residual, float* y, void* workspace,
-                    size_t workspace_bytes, dvcStream stream, float* pool = nullptr, long pool_batch_stride = 0) {
+// Everything of a Winograd launch but the launch: argument checks, the kernel's argument block, the plan.  `*m_out` /
+// `*tr_out`: workgroup shape and tile-block shape; `*group_out`: images one launch covers.
+static int wino_setup(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x, const float* x2, const float* u_packed,
+                      const float* bias, const float* act_slope_ptr, const float* residual, float* y, void* workspace,
+                      size_t workspace_bytes, float* pool, long pool_batch_stride, ConvWinoArgs& s, int* m_out, int* tr_out,
+                      int* group_out) {
     DVC_REQUIRE(d && x && u_packed && (y || pool), "dvc_conv2d_winograd: null argument");
     DVC_REQUIRE(d->ksize == 3 && d->stride == 1 && (d->dil == 1 || d->dil == 2) && d->pad == d->dil,
                 "dvc_conv2d_winograd: needs a 3x3 stride-1 layer with pad == dilation (1 or 2)");
@@ -585,7 +588,6 @@ static int wino_run(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x,
     DVC_REQUIRE((reinterpret_cast<uintptr_t>(u_packed) & 15) == 0, "dvc_conv2d_winograd: weights must be 16-byte aligned");
     DVC_REQUIRE((long)d->Cin * d->H * d->W * 4 < (1L << 31) && (long)d->Cin * 2048 * 4 < (1L << 31),
                 "dvc_conv2d_winograd: tensor too large for buffer-descriptor staging");
-    ConvWinoArgs s;
     s.x2 = nullptr; s.x2_bs = 0; s.cinA = d->Cin; s.H2 = s.W2 = s.VH2 = s.VW2 = 0; s.in_up2 = s.in_sub2 = 1;
     ConvKArgs& a = s.k;
     a.x = x; a.w = u_packed; a.bias = bias; a.in_scale = nullptr; a.in_shift = nullptr;
@@ -635,8 +637,6 @@ static int wino_run(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x,
     a.part = reinterpret_cast<float*>(workspace);
     s.gx = s.ss * s.ss * s.blk_y * s.blk_x;
     s.gy = d->Cout / (32 * wm);
-    hipStream_t st = (hipStream_t)stream;
-    const long OHW = (long)OH * OW, per_img = (long)d->Cout * OHW;
     // images per launch: all of them, unless the workspace holds the partial outputs of fewer at this (single-image) split
     const int group = wino_images_per_launch(d, OH, OW, best_m, best_tr, a.split, workspace_bytes);
     DVC_REQUIRE(group >= 0, "dvc_conv2d_winograd: %ld workgroups per image (feature map too large for this path)",
@@ -647,6 +647,60 @@ static int wino_run(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x,
     DVC_REQUIRE(!(d->flags & DVC_CONV_DEFER_REDUCE) || a.split == 1 || !residual,
                 "dvc_conv2d_winograd: DVC_CONV_DEFER_REDUCE does not carry a residual");
     s.pool_bs = pool_batch_stride ? pool_batch_stride : (long)d->Cout * (OH / 2) * (OW / 2);
+    s.pool = pool;
+    *m_out = best_m; *tr_out = best_tr; *group_out = group;
+    return 0;
+}
+
+// the decode reciprocals and the grid of a launch over `NB` images (s.k.N etc. already set)
+static dim3 wino_finish_grid(ConvWinoArgs& s, int NB) {
+    s.gz = NB * s.k.split;
+    s.m_gxy = wino_magic((long)s.gx * s.gy);
+    s.m_gx = wino_magic(s.gx);
+    s.m_cls = wino_magic((long)s.blk_y * s.blk_x);
+    s.m_blkx = wino_magic(s.blk_x);
+    s.m_split = wino_magic(s.k.split);
+    return dim3((unsigned)(s.gx * s.gy * s.gz));      // 1-D: the kernel maps it XCD-aware onto (gx, gy, gz)
+}
+
+// the launch(es) that follow a split Winograd launch over `NB` images: split-K reduce (+ pool), unless deferred
+static int wino_reduce(const DvcConvDesc* d, const ConvWinoArgs& s, int NB, int OH, int OW, const float* bias,
+                       const float* act_slope_ptr, hipStream_t st) {
+    const ConvKArgs& a = s.k;
+    const long OHW = (long)OH * OW, per_img = (long)d->Cout * OHW;
+    if (a.split > 1 && s.pool) {
+        const long windows = (long)d->Cout * ((OH + 1) / 2) * ((OW + 1) / 2);
+        hipLaunchKernelGGL(conv_splitk_reduce_pool_kernel, dim3((unsigned)((windows + 255) / 256), NB), dim3(256), 0, st, a.part,
+                           a.split, (long)NB * per_img, d->Cout, OH, OW, bias, d->act, d->act_slope, act_slope_ptr, a.y, a.y_bs,
+                           s.pool, s.pool_bs);
+        DVC_CHECK_LAUNCH("dvc_conv2d_winograd_pool(split-K reduce)");
+    } else if (a.split > 1 && !(d->flags & DVC_CONV_DEFER_REDUCE)) {
+        const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)NB * per_img) % 4 == 0);
+        if (v4)
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)((per_img / 4 + 255) / 256), NB), dim3(256), 0, st,
+                               a.part, a.split, (long)NB * per_img, d->Cout, OHW, bias, a.res, a.res_bs, d->act,
+                               d->act_slope, act_slope_ptr, a.y, a.y_bs);
+        else
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3((unsigned)((per_img + 255) / 256), NB), dim3(256), 0, st,
+                               a.part, a.split, (long)NB * per_img, d->Cout, OHW, bias, a.res, a.res_bs, d->act,
+                               d->act_slope, act_slope_ptr, a.y, a.y_bs);
+        DVC_CHECK_LAUNCH("dvc_conv2d_winograd(split-K reduce)");
+    }
+    return 0;
+}
+
+static int wino_run(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x, const float* x2, const float* u_packed,
+                    const float* bias, const float* act_slope_ptr, const float* residual, float* y, void* workspace,
+                    size_t workspace_bytes, dvcStream stream, float* pool = nullptr, long pool_batch_stride = 0) {
+    ConvWinoArgs s;
+    int best_m = -1, best_tr = 1, group = 0;
+    if (int rc = wino_setup(d, d2, x, x2, u_packed, bias, act_slope_ptr, residual, y, workspace, workspace_bytes, pool,
+                            pool_batch_stride, s, &best_m, &best_tr, &group))
+        return rc;
+    ConvKArgs& a = s.k;
+    int32_t OH, OW;
+    dvc_conv2d_out_hw(d, &OH, &OW);
+    hipStream_t st = (hipStream_t)stream;
     for (int n0 = 0; n0 < d->N; n0 += group) {
         const int NB = std::min(group, d->N - n0);
         a.N = NB;
@@ -655,38 +709,75 @@ static int wino_run(const DvcConvDesc* d, const DvcConvDesc* d2, const float* x,
         a.y = y ? y + (long)n0 * a.y_bs : nullptr;
         s.pool = pool ? pool + (long)n0 * s.pool_bs : nullptr;
         a.res = residual ? residual + (long)n0 * a.res_bs : nullptr;
-        s.gz = NB * a.split;
-        DVC_REQUIRE((long)s.gx * s.gy * s.gz < (1L << 31), "dvc_conv2d_winograd: grid too large");
-        s.m_gxy = wino_magic((long)s.gx * s.gy);
-        s.m_gx = wino_magic(s.gx);
-        s.m_cls = wino_magic((long)s.blk_y * s.blk_x);
-        s.m_blkx = wino_magic(s.blk_x);
-        s.m_split = wino_magic(a.split);
-        dim3 grid((unsigned)(s.gx * s.gy * s.gz));      // 1-D: the kernel maps it XCD-aware onto (gx, gy, gz)
+        DVC_REQUIRE((long)s.gx * s.gy * NB * a.split < (1L << 31), "dvc_conv2d_winograd: grid too large");
+        const dim3 grid = wino_finish_grid(s, NB);
         if (d2) conv_wino_launch_m1_dual(best_tr, grid, st, s);
         else if (best_m == 0) conv_wino_launch_m4(best_tr, grid, st, s);
         else if (best_m == 1) conv_wino_launch_m2(best_tr, grid, st, s);
         else if (best_m == 2) conv_wino_launch_m1(best_tr, grid, st, s);
         else conv_wino_launch_m0(best_tr, grid, st, s);
         DVC_CHECK_LAUNCH("dvc_conv2d_winograd");
-        if (a.split > 1 && pool) {
-            const long windows = (long)d->Cout * ((OH + 1) / 2) * ((OW + 1) / 2);
-            hipLaunchKernelGGL(conv_splitk_reduce_pool_kernel, dim3((unsigned)((windows + 255) / 256), NB), dim3(256), 0, st, a.part,
-                               a.split, (long)NB * per_img, d->Cout, OH, OW, bias, d->act, d->act_slope, act_slope_ptr, a.y, a.y_bs,
-                               s.pool, s.pool_bs);
-            DVC_CHECK_LAUNCH("dvc_conv2d_winograd_pool(split-K reduce)");
-        } else if (a.split > 1 && !(d->flags & DVC_CONV_DEFER_REDUCE)) {
-            const bool v4 = (OHW % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.part) & 15) == 0) && (((long)NB * per_img) % 4 == 0);
-            if (v4)
-                hipLaunchKernelGGL(conv_splitk_reduce_kernel<4>, dim3((unsigned)((per_img / 4 + 255) / 256), NB), dim3(256), 0, st,
-                                   a.part, a.split, (long)NB * per_img, d->Cout, OHW, bias, a.res, a.res_bs, d->act,
-                                   d->act_slope, act_slope_ptr, a.y, a.y_bs);
-            else
-                hipLaunchKernelGGL(conv_splitk_reduce_kernel<1>, dim3((unsigned)((per_img + 255) / 256), NB), dim3(256), 0, st,
-                                   a.part, a.split, (long)NB * per_img, d->Cout, OHW, bias, a.res, a.res_bs, d->act,
-                                   d->act_slope, act_slope_ptr, a.y, a.y_bs);
-            DVC_CHECK_LAUNCH("dvc_conv2d_winograd(split-K reduce)");
+        if (int rc = wino_reduce(d, s, NB, OH, OW, bias, act_slope_ptr, st)) return rc;
+    }
+    return 0;
+}
+
+// Several independent Winograd layers as ONE launch (conv_wino_group_kernel).  Every item is planned exactly as
+// dvc_conv2d_winograd plans it alone; when all of them get the 64-channel x 32-tile workgroup shape and one launch each, their
+// workgroups form one grid (longest workgroups first), followed by the items' own reduce launches where a split item does not
+// defer its reduce.  Otherwise (another shape, a batch that needs several launches): one launch per item, as if called apart.
+extern "C" int dvc_conv2d_winograd_group(const DvcConvGroupItem* items, int32_t n_items, dvcStream stream) {
+    DVC_REQUIRE(items && n_items >= 1 && n_items <= WINO_GROUP_MAX, "dvc_conv2d_winograd_group: 1..%d items", WINO_GROUP_MAX);
+    hipStream_t st = (hipStream_t)stream;
+    ConvWinoGroupArgs g;
+    int OHs[WINO_GROUP_MAX], OWs[WINO_GROUP_MAX], order[WINO_GROUP_MAX];
+    ConvWinoArgs tmp[WINO_GROUP_MAX];
+    int trs[WINO_GROUP_MAX];
+    bool together = n_items > 1;
+    for (int i = 0; i < n_items; ++i) {
+        const DvcConvGroupItem& it = items[i];
+        DVC_REQUIRE(it.x && it.u_packed && it.y, "dvc_conv2d_winograd_group: null argument in item %d", i);
+        for (int j = 0; j < i; ++j)
+            DVC_REQUIRE(it.y != items[j].y && (!it.workspace || it.workspace != items[j].workspace),
+                        "dvc_conv2d_winograd_group: items %d and %d share an output or a workspace", j, i);
+        int m = -1, grp = 0;
+        if (int rc = wino_setup(&it.d, nullptr, it.x, nullptr, it.u_packed, it.bias, it.act_slope_ptr, it.residual, it.y, it.workspace,
+                                it.workspace_bytes, nullptr, 0, tmp[i], &m, &trs[i], &grp))
+            return rc;
+        int32_t oh, ow;
+        dvc_conv2d_out_hw(&it.d, &oh, &ow);
+        OHs[i] = oh; OWs[i] = ow;
+        if (m != 2 || grp < it.d.N) together = false;
+        order[i] = i;
+    }
+    if (!together) {
+        for (int i = 0; i < n_items; ++i) {
+            const DvcConvGroupItem& it = items[i];
+            if (int rc = wino_run(&it.d, nullptr, it.x, nullptr, it.u_packed, it.bias, it.act_slope_ptr, it.residual, it.y, it.workspace,
+                                  it.workspace_bytes, stream))
+                return rc;
         }
+        return 0;
+    }
+    // longest workgroups first (chunks per split): the short ones fill the tail
+    std::sort(order, order + n_items, [&](int a, int b) {
+        return tmp[a].k.chunks_per_split != tmp[b].k.chunks_per_split ? tmp[a].k.chunks_per_split > tmp[b].k.chunks_per_split : a < b;
+    });
+    g.n = n_items;
+    g.per_xcd[0] = 0;
+    for (int k = 0; k < WINO_GROUP_MAX; ++k) {
+        const int i = order[k < n_items ? k : n_items - 1];
+        g.item[k] = tmp[i];
+        g.tr[k] = trs[i];
+        const dim3 grid = wino_finish_grid(g.item[k], items[i].d.N);
+        g.per_xcd[k + 1] = g.per_xcd[k] + (k < n_items ? cdiv((int)grid.x, 8) : 0);
+    }
+    DVC_REQUIRE((long)g.per_xcd[n_items] * 8 < (1L << 31), "dvc_conv2d_winograd_group: grid too large");
+    conv_wino_launch_group_m1(dim3((unsigned)(g.per_xcd[n_items] * 8)), st, g);
+    DVC_CHECK_LAUNCH("dvc_conv2d_winograd_group");
+    for (int k = 0; k < n_items; ++k) {
+        const int i = order[k];
+        if (int rc = wino_reduce(&items[i].d, g.item[k], items[i].d.N, OHs[i], OWs[i], items[i].bias, items[i].act_slope_ptr, st)) return rc;
     }
     return 0;
 }

@@ -143,10 +143,23 @@ __device__ __forceinline__ int wino_stored_offset(int VH, int VW, int W, int in_
     return sy * W + sx;
 }
 
-template <int WM, int WN, int TR, int KC, int VAR = 0, bool DUAL = false>
-__global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_kernel(ConvWinoArgs s) {
+// LDS of one workgroup (floats): NBUF staged patches + NBUF filter slices (the output exchange reuses the filter buffers)
+#define WINO_NBUF 3                             // chunks c+1 and c+2 are in flight under the arithmetic of chunk c
+__host__ __device__ constexpr int wino_xs_floats(int wm, int wn, int tr, int kc) {
+    return ((kc * (2 * tr * wn + 2) * wino_pitch(tr) + 128 * wm * wn - 1) / (128 * wm * wn)) * (128 * wm * wn);
+}
+__host__ __device__ constexpr int wino_us_floats(int wm, int kc) { return wm * kc * 128 * 4; }
+
+// The kernel body: workgroup `wlog` (logical index, 0 .. gx * gy * gz - 1) of the launch described by `s`, staging through the
+// LDS arrays `xsb` (WINO_NBUF * wino_xs_floats) and `usb` (WINO_NBUF * wino_us_floats).  Shared by the one-layer kernel below
+// and by conv_wino_group_kernel (several independent layers in one launch).
+// SA = ConvWinoArgs in the address space the caller holds it in: generic (a by-value kernel argument) or the kernel-argument
+// segment itself (address space 4, the group kernel's item table: every field read stays a scalar load from constant memory —
+// a generic reference to a dynamically selected item makes the compiler copy the whole table to scratch).
+template <int WM, int WN, int TR, int KC, int VAR = 0, bool DUAL = false, class SA = ConvWinoArgs>
+__device__ __forceinline__ void conv_wino_body(const SA& s, const int wlog, float* const xsb, float* const usb) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const ConvKArgs& a = s.k;
+    const auto& a = s.k;
     constexpr int NPAIR = WM * WN;              // wave pairs = (32 channels x 32 tiles) blocks of the workgroup
     constexpr int NT = 128 * NPAIR;
     constexpr int TC = 32 / TR;
@@ -156,7 +169,9 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
     constexpr int plane = PR * PITCH;
     constexpr int EPT = (KC * plane + NT - 1) / NT;
     constexpr int C_XS = EPT * NT;
+    static_assert(C_XS == wino_xs_floats(WM, WN, TR, KC), "LDS size helper out of step");
     constexpr int UQ = WM * KC * 128;
+    static_assert(UQ * 4 == wino_us_floats(WM, KC), "LDS size helper out of step");
     static_assert(UQ % NT == 0, "whole staging instructions");
     static_assert(PITCH >= PC && PITCH % 2 == 0 && plane % 2 == 0 && KC % 4 == 0, "aligned patch rows, even K-steps per chunk");
     static_assert(2 * (PITCH / 2) + 1 < 256, "ds_read2_b64 offsets are 8 bits");
@@ -164,10 +179,8 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
     constexpr int NI = EPT + WPT;
     static_assert(2 * NI < 64, "vmcnt is 6 bits");
     constexpr int KS = KC / 2;
-    constexpr int NBUF = 3;                     // chunks c+1 and c+2 are in flight under the arithmetic of chunk c
+    constexpr int NBUF = WINO_NBUF;
     constexpr int OOB = (int)0x80000000;
-    __shared__ __attribute__((aligned(16))) float xsb[NBUF * C_XS];
-    __shared__ __attribute__((aligned(16))) float usb[NBUF * UQ * 4];
     static_assert(NBUF * UQ * 4 >= 2 * NPAIR * 32 * 64, "the output exchange fits in the filter buffers");
 
     const int tid = threadIdx.x;
@@ -177,13 +190,6 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
     const int wm = pair / WN, wn = pair % WN;
     const int tr = l31 / TC, tc = l31 % TC;
     const int ss = s.ss;
-    // XCD-aware order (speed only): the dispatcher places workgroup b of the 1-D launch on XCD b % 8 and every XCD has
-    // its own L2.  The workgroups of one XCD get CONSECUTIVE logical indices, tile blocks fastest: they share one (channel
-    // block, input-channel split) filter slice, which then comes from HBM / the Infinity Cache once per XCD that uses it
-    // instead of once per XCD (512 -> 512 channels at 27x48: 145 -> ~40 MB per launch).  Bijective for any grid size.
-    const int G = s.gx * s.gy * s.gz;
-    const int xq = G / 8, xr = G % 8, xcd = blockIdx.x % 8, xi = blockIdx.x / 8;
-    const int wlog = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
     // (the decode is all wave-uniform integer division: by multiplication with host-made reciprocals — a plain `/` costs ~35
     // instructions each here, and the prologue is instruction-bound: ~1.5 us of every workgroup's 32)
     const int bz = wino_div(wlog, s.m_gxy), r_xy = wlog - bz * (s.gx * s.gy);
@@ -520,6 +526,70 @@ __global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2
 #endif
 }
 
+template <int WM, int WN, int TR, int KC, int VAR = 0, bool DUAL = false>
+__global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_kernel(ConvWinoArgs s) {
+    __shared__ __attribute__((aligned(16))) float xsb[WINO_NBUF * wino_xs_floats(WM, WN, TR, KC)];
+    __shared__ __attribute__((aligned(16))) float usb[WINO_NBUF * wino_us_floats(WM, KC)];
+    // XCD-aware order (speed only): the dispatcher places workgroup b of the 1-D launch on XCD b % 8 and every XCD has
+    // its own L2.  The workgroups of one XCD get CONSECUTIVE logical indices, tile blocks fastest: they share one (channel
+    // block, input-channel split) filter slice, which then comes from HBM / the Infinity Cache once per XCD that uses it
+    // instead of once per XCD (512 -> 512 channels at 27x48: 145 -> ~40 MB per launch).  Bijective for any grid size.
+    const int G = s.gx * s.gy * s.gz;
+    const int xq = G / 8, xr = G % 8, xcd = blockIdx.x % 8, xi = blockIdx.x / 8;
+    const int wlog = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    conv_wino_body<WM, WN, TR, KC, VAR, DUAL>(s, wlog, xsb, usb);
+}
+
+// ---- several INDEPENDENT layers in one launch (dvc_conv2d_winograd_group): WarpNet's four heads (NonlocalNet.py:451-458) are
+// mutually independent, each fills the chip for about one round of workgroups with a prologue, a K loop and an epilogue that
+// all of its workgroups run in lock step, and the small ones (13x24, 27x48 maps) cannot fill it at all.  As ONE grid the
+// workgroups of the layers stream through the CUs back to back: different layers' workgroups have different lengths, so the
+// prologue / epilogue of one overlaps the K loop of its CU neighbour, the small layers ride in the gaps, and three launch
+// ramps and tails disappear.  Every item keeps the plan (tile-block shape TR, split over input channels) it would get alone
+// and runs the same body: results are bit-identical to the per-layer launches.
+// Grid: every item's workgroup count rounded up to a multiple of 8; XCD x (blockIdx.x % 8) walks item 0's x-th eighth, then
+// item 1's, ...: each layer is spread over all XCDs (an XCD-contiguous split of the whole grid would give XCD 0 nothing but the
+// longest layer), and within an XCD consecutive workgroups still share a filter slice.
+#define WINO_GROUP_MAX 4
+struct ConvWinoGroupArgs {
+    ConvWinoArgs item[WINO_GROUP_MAX];
+    int per_xcd[WINO_GROUP_MAX + 1];   // prefix sums of ceil(G_i / 8)
+    int tr[WINO_GROUP_MAX];
+    int n;
+};
+typedef __attribute__((address_space(4))) ConvWinoArgs ConvWinoArgsK;     // ... as it lies in the kernel-argument segment
+template <int WM, int WN, int KC>
+__global__ __launch_bounds__(128 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_group_kernel(ConvWinoGroupArgs g) {
+    constexpr int XS = wino_xs_floats(WM, WN, 1, KC) > wino_xs_floats(WM, WN, 8, KC) ? wino_xs_floats(WM, WN, 1, KC) : wino_xs_floats(WM, WN, 8, KC);
+    static_assert(XS >= wino_xs_floats(WM, WN, 2, KC) && XS >= wino_xs_floats(WM, WN, 4, KC), "largest patch buffer");
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float xsb[WINO_NBUF * XS];
+    __shared__ __attribute__((aligned(16))) float usb[WINO_NBUF * wino_us_floats(WM, KC)];
+    const int xcd = blockIdx.x % 8, xi = blockIdx.x / 8;
+    // (compile-time indices only: a dynamic index into the by-value argument block would move it to scratch)
+    int it = 0, base = 0, q = g.per_xcd[1], tr = g.tr[0];
+#pragma unroll
+    for (int i = 1; i < WINO_GROUP_MAX; ++i)
+        if (i < g.n && xi >= g.per_xcd[i]) {
+            it = i;
+            base = g.per_xcd[i];
+            q = g.per_xcd[i + 1] - g.per_xcd[i];
+            tr = g.tr[i];
+        }
+    const int wlog = xcd * q + (xi - base);
+    // item `it` where it lies in the kernel-argument segment (item[] is the first member of the only argument)
+    static_assert(__builtin_offsetof(ConvWinoGroupArgs, item) == 0, "item table at the start of the argument block");
+    const ConvWinoArgsK& s = ((const ConvWinoArgsK*)__builtin_amdgcn_kernarg_segment_ptr())[it];
+    if (wlog >= s.gx * s.gy * s.gz) return;       // padding workgroup of this item's last eighth
+    switch (tr) {
+        case 1: conv_wino_body<WM, WN, 1, KC, 0, false, ConvWinoArgsK>(s, wlog, xsb, usb); break;
+        case 2: conv_wino_body<WM, WN, 2, KC, 0, false, ConvWinoArgsK>(s, wlog, xsb, usb); break;
+        case 4: conv_wino_body<WM, WN, 4, KC, 0, false, ConvWinoArgsK>(s, wlog, xsb, usb); break;
+        default: conv_wino_body<WM, WN, 8, KC, 0, false, ConvWinoArgsK>(s, wlog, xsb, usb); break;
+    }
+#endif
+}
+
 template <int WM, int WN, int KC>
 static void conv_wino_launch_shape(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s) {
     constexpr int NT = 128 * WM * WN;
@@ -579,3 +649,4 @@ void conv_wino_launch_m4(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& 
 void conv_wino_launch_m2(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s);   // 64 channels x 64 tiles, 8 waves
 void conv_wino_launch_m1(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s);   // 64 channels x 32 tiles, 4 waves, two per CU
 void conv_wino_launch_m0(int tr, dim3 grid, hipStream_t st, const ConvWinoArgs& s);   // 32 channels x 32 tiles, 2 waves, four per CU
+void conv_wino_launch_group_m1(dim3 grid, hipStream_t st, const ConvWinoGroupArgs& g);  // several layers, 64 x 32 shape (conv_wino_group.hip)

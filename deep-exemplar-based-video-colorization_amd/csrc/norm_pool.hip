@@ -2,6 +2,7 @@
 // nearest upsampling and the channel L2 normalisation.  All are deterministic (no atomics):
 // reductions are wave shuffles + one LDS hop, so repeated runs are bit-identical.
 #include "common.h"
+#include <algorithm>
 
 thread_local char g_dvc_err[512] = {0};
 char* dvc_err_buf() { return g_dvc_err; }
@@ -325,6 +326,119 @@ extern "C" int dvc_instnorm_apply_partials(const float* part, int32_t S, const f
                        chan_scale, eps, C, H, W, up, sub, rpad, rbs, ybs, y, scale_out, shift_out, chan_scale2, y2 ? sub2 : 1,
                        (long)C * (sub2 == 2 ? (H + 1) / 2 : H) * (sub2 == 2 ? (W + 1) / 2 : W), y2);
     DVC_CHECK_LAUNCH("dvc_instnorm_apply_partials");
+    return 0;
+}
+
+// ---- several independent InstanceNorm (+ PReLU / upsample / pad) launches as one (r06): the norms between and behind the two
+// convolutions of WarpNet's four heads (NonlocalNet.py:364-410) are mutually independent, 64-256 planes each — four launches of
+// ~8 us that cannot fill the chip one by one.  One workgroup per (item, n, c) plane, the bodies of the two kernels above
+// (an item is either a tensor or the split-K partial sums of a convolution): bit-identical to the per-item launches, whose
+// statistics do not depend on the block size (plane_stats).
+#define INSTNORM_GROUP_MAX 4
+struct InstNormGroupArgs {
+    DvcInstNormItem item[INSTNORM_GROUP_MAX];
+    int start[INSTNORM_GROUP_MAX + 1];     // prefix sums of N * C
+    int n;
+};
+__global__ __launch_bounds__(1024) void instnorm_group_kernel(InstNormGroupArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ double red[36];
+    extern __shared__ __attribute__((aligned(16))) float plane[];   // the largest H * W among the partial-sum items
+    // (compile-time indices only, and the selected item read where it lies in the kernel-argument segment: a dynamic index into
+    // the by-value argument block would move the whole block to scratch)
+    int k = 0, first = 0;
+#pragma unroll
+    for (int i = 1; i < INSTNORM_GROUP_MAX; ++i)
+        if (i < g.n && (int)blockIdx.x >= g.start[i]) {
+            k = i;
+            first = g.start[i];
+        }
+    static_assert(__builtin_offsetof(InstNormGroupArgs, item) == 0, "item table at the start of the argument block");
+    typedef __attribute__((address_space(4))) DvcInstNormItem ItemK;
+    const ItemK& t = ((const ItemK*)__builtin_amdgcn_kernarg_segment_ptr())[k];
+    const int p = blockIdx.x - first;  // n*C + c
+    const int C = t.C, H = t.H, W = t.W, HW = H * W;
+    const int n = p / C, c = p - n * C;
+    const float* xp;
+    if (t.S == 0) {
+        xp = t.x + (long)n * t.x_batch_stride + (long)c * HW;
+    } else {
+        const int S = t.S;
+        const long slab = (long)t.N * C * HW;
+        const float* p0 = t.x + (long)p * HW;
+        const float b = t.bias ? t.bias[c] : 0.f;
+        const float aslope = t.act_slope_ptr ? *t.act_slope_ptr : t.act_slope;
+        const int act = t.act;
+        auto finish = [&](float v) {
+            v += b;
+            if (act == DVC_ACT_RELU) v = v > 0.f ? v : 0.f;
+            else if (act == DVC_ACT_PRELU || act == DVC_ACT_LEAKY) v = v >= 0.f ? v : v * aslope;
+            return v;
+        };
+        // (exactly instnorm_apply_partials_kernel's summation)
+        const bool v4 = (HW % 4 == 0) && (slab % 4 == 0) && ((reinterpret_cast<uintptr_t>(t.x) & 15) == 0);
+        const int HW4 = v4 ? HW : 0;
+        for (int i = threadIdx.x * 4; i < HW4; i += blockDim.x * 4) {
+            float4 tt[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tt[q] = q < S ? *reinterpret_cast<const float4*>(p0 + (long)q * slab + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { v.x += tt[q].x; v.y += tt[q].y; v.z += tt[q].z; v.w += tt[q].w; }
+            *reinterpret_cast<float4*>(plane + i) = make_float4(finish(v.x), finish(v.y), finish(v.z), finish(v.w));
+        }
+        for (int i = HW4 + threadIdx.x; i < HW; i += blockDim.x) {
+            float v = 0.f;
+            for (int q = 0; q < S; ++q) v += p0[(long)q * slab + i];
+            plane[i] = finish(v);
+        }
+        __syncthreads();
+        xp = plane;
+    }
+    instnorm_apply_plane(xp, p, n, c, red, t.residual, t.slope_ptr, t.chan_scale, t.eps, C, H, W, t.up, t.sub, t.rpad,
+                         t.res_batch_stride, t.y_batch_stride, t.y, nullptr, nullptr, nullptr, 1, 0, nullptr);
+#endif
+}
+
+extern "C" int dvc_instnorm_apply_group(const DvcInstNormItem* items, int32_t n_items, dvcStream stream) {
+    DVC_REQUIRE(items && n_items >= 1 && n_items <= INSTNORM_GROUP_MAX, "dvc_instnorm_apply_group: 1..%d items", INSTNORM_GROUP_MAX);
+    InstNormGroupArgs g;
+    g.n = n_items;
+    g.start[0] = 0;
+    size_t lds = 0;
+    int block = 512;
+    for (int i = 0; i < INSTNORM_GROUP_MAX; ++i) {
+        const DvcInstNormItem& src = items[i < n_items ? i : n_items - 1];
+        DvcInstNormItem& t = g.item[i];
+        t = src;
+        if (i >= n_items) {
+            g.start[i + 1] = g.start[i];
+            continue;
+        }
+        DVC_REQUIRE(t.x && t.y && t.S >= 0 && t.S <= 8 && t.N > 0 && t.C > 0 && t.H > 0 && t.W > 0,
+                    "dvc_instnorm_apply_group: bad argument in item %d", i);
+        DVC_REQUIRE(t.up >= 1 && t.up <= 4 && (t.sub == 1 || t.sub == 2) && t.rpad >= 0 && !(t.up != 1 && t.sub != 1),
+                    "dvc_instnorm_apply_group: bad up/sub/rpad in item %d", i);
+        DVC_REQUIRE(!(t.residual && (t.up != 1 || t.sub != 1)), "dvc_instnorm_apply_group: residual requires up == sub == 1 (item %d)", i);
+        DVC_REQUIRE(!(t.S == 0 && t.x == t.y && (t.up != 1 || t.sub != 1 || t.rpad != 0)),
+                    "dvc_instnorm_apply_group: in place needs up == sub == 1, rpad == 0 (item %d)", i);
+        const long HW = (long)t.H * t.W;
+        if (t.S >= 1) {
+            DVC_REQUIRE(HW <= 16384, "dvc_instnorm_apply_group: plane of %d x %d does not fit the LDS image (item %d)", t.H, t.W, i);
+            DVC_REQUIRE(t.act == DVC_ACT_NONE || t.act == DVC_ACT_RELU || t.act == DVC_ACT_PRELU || t.act == DVC_ACT_LEAKY,
+                        "dvc_instnorm_apply_group: unsupported activation %d (item %d)", t.act, i);
+            lds = std::max(lds, (size_t)HW * sizeof(float));
+        }
+        if (HW >= 4096) block = 1024;
+        const long VH = t.sub == 2 ? (t.H + 1) / 2 : (long)t.H * t.up, VW = t.sub == 2 ? (t.W + 1) / 2 : (long)t.W * t.up;
+        if (!t.x_batch_stride) t.x_batch_stride = (long)t.C * HW;
+        if (!t.res_batch_stride) t.res_batch_stride = (long)t.C * HW;
+        if (!t.y_batch_stride) t.y_batch_stride = (long)t.C * (VH + 2 * t.rpad) * VW;
+        DVC_REQUIRE((long)g.start[i] + (long)t.N * t.C < (1L << 31), "dvc_instnorm_apply_group: too many planes");
+        g.start[i + 1] = g.start[i] + t.N * t.C;
+    }
+    hipLaunchKernelGGL(instnorm_group_kernel, dim3(g.start[n_items]), dim3(block), lds, (hipStream_t)stream, g);
+    DVC_CHECK_LAUNCH("dvc_instnorm_apply_group");
     return 0;
 }
 

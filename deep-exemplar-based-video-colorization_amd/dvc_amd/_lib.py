@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DVC_DEBUG_LIB=1 (tools/ only) loads the -DDVC_DEBUG build, the only one that carries the dvc_debug_* hooks
 DEBUG_BUILD = os.environ.get("DVC_DEBUG_LIB", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "libdvc_hip_debug.so" if DEBUG_BUILD else "libdvc_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -26,6 +26,24 @@ class DvcConvDesc(ctypes.Structure):
         ("act", c_i32), ("act_slope", ctypes.c_float), ("in_prelu", c_i32), ("cfg", c_i32), ("split_k", c_i32),
         ("x_batch_stride", c_i64), ("y_batch_stride", c_i64), ("res_batch_stride", c_i64),
         ("flags", c_i32), ("w_batch_stride", c_i64),
+    ]
+
+
+class DvcConvGroupItem(ctypes.Structure):
+    _fields_ = [
+        ("d", DvcConvDesc), ("x", ctypes.c_void_p), ("u_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("act_slope_ptr", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("y", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
+class DvcInstNormItem(ctypes.Structure):
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("S", c_i32), ("bias", ctypes.c_void_p), ("act", c_i32), ("act_slope", ctypes.c_float),
+        ("act_slope_ptr", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("slope_ptr", ctypes.c_void_p),
+        ("chan_scale", ctypes.c_void_p), ("eps", ctypes.c_float),
+        ("N", c_i32), ("C", c_i32), ("H", c_i32), ("W", c_i32), ("up", c_i32), ("sub", c_i32), ("rpad", c_i32),
+        ("x_batch_stride", c_i64), ("res_batch_stride", c_i64), ("y_batch_stride", c_i64), ("y", ctypes.c_void_p),
     ]
 
 
@@ -47,6 +65,8 @@ SIGNATURES = {
                                                 ctypes.c_size_t, _VP]),
     "dvc_conv2d_winograd_dual": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP,
                                                 _VP, _VP, ctypes.c_size_t, _VP]),
+    "dvc_conv2d_winograd_group": (ctypes.c_int, [ctypes.POINTER(DvcConvGroupItem), c_i32, _VP]),
+    "dvc_instnorm_apply_group": (ctypes.c_int, [ctypes.POINTER(DvcInstNormItem), c_i32, _VP]),
     "dvc_conv1x1_small": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, _VP, _VP]),
     "dvc_instnorm_stats": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, c_i64, ctypes.c_float, _VP, _VP, _VP, _VP]),
     "dvc_affine_act": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,

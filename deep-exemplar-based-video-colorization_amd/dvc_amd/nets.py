@@ -307,27 +307,48 @@ class WarpNet(nn.Module):
                                    f"layer2_1 gives {(h, w)}")
         trunk = torch.empty((N, arch.WARP_TRUNK_CH, h, w), device=dev, dtype=torch.float32)
         bs = arch.WARP_TRUNK_CH * h * w
+        # The four heads are mutually independent (NonlocalNet.py:451-458): they advance stage by stage — first convolutions,
+        # their norms, second convolutions, final norms into the trunk's channel slices — and each stage is ONE launch over the
+        # heads that take the same kind of kernel (ops.conv3x3_group / ops.instnorm_apply_group: bit-identical to per-layer
+        # launches, which DVC_GROUP_HEADS=0 brings back).  The stride-2 head (layer2_1, run-time-geometry direct kernel with
+        # the norm applied on load) keeps its own launches.
+        heads = []
         for i, (name, x) in enumerate(zip(arch.WARP_HEAD_ORDER, feats)):
             spec = arch.WARP_HEADS[name]
             seq = getattr(self, name)
             (ia, _, _, _, pa), (ib, _, _, sb, pb) = spec["convs"]
-            ca, cb = seq[ia], seq[ib]
-            t = self._conv3(f"{name}.{ia}", ca, x, pad_mode=ops.PAD_REFLECT, defer_reduce=sb == 1)
-            # InstanceNorm + PReLU are materialised (one launch, in place) so that the next convolution
-            # has no fused input transform and stages through LDS-DMA; the stride-2 convolution
-            # (run-time-geometry kernel, register staging anyway) applies them on load instead
-            if sb == 1:
-                t = _norm_in_place(t, slope_t=seq[pa].weight.detach())
-                t = self._conv3(f"{name}.{ib}", cb, t, pad_mode=ops.PAD_REFLECT, in_up=2 if spec["up_mid"] else 1,
-                                defer_reduce=True)
-            else:
-                sc, sh = ops.instnorm_stats(t)
-                t = ops.conv2d(t, self._pk(f"{name}.{ib}", cb), cb.bias.detach(), stride=sb,
-                               pad_mode=ops.PAD_REFLECT, in_up=2 if spec["up_mid"] else 1,
-                               in_scale=sc, in_shift=sh, in_slope_t=seq[pa].weight.detach())
-            dst = trunk[:, i * arch.WARP_FEATURE_CH:(i + 1) * arch.WARP_FEATURE_CH]
-            ops.instnorm_apply(t, slope_t=seq[pb].weight.detach(), up=2 if spec["up_out"] else 1,
-                               rpad=rpad5 if name == "layer5_1" else 0, out=dst, out_batch_stride=bs)
+            heads.append(dict(i=i, name=name, spec=spec, seq=seq, ia=ia, pa=pa, ib=ib, sb=sb, pb=pb, ca=seq[ia], cb=seq[ib], x=x))
+
+        def conv_item(key, conv, x, **kw):
+            return dict(x=x, weight=conv.weight, packs=_packs(self._cache, key, conv.weight), bias=conv.bias.detach(),
+                        layer="warp." + key, pad_mode=ops.PAD_REFLECT, **kw)
+
+        # stage 1: first convolutions
+        t1 = ops.conv3x3_group([conv_item(f"{hd['name']}.{hd['ia']}", hd["ca"], hd["x"], defer_reduce=hd["sb"] == 1) for hd in heads])
+        # stage 2: InstanceNorm + PReLU, materialised (one launch, in place where the convolution wrote a tensor) so that the
+        # next convolution has no fused input transform and stages through LDS-DMA; the stride-2 convolution (register
+        # staging anyway) applies them on load instead
+        plain = [k for k, hd in enumerate(heads) if hd["sb"] == 1]
+        normed = ops.instnorm_apply_group([dict(x=t1[k], out=None if isinstance(t1[k], ops.ConvPartials) else t1[k],
+                                                slope_t=heads[k]["seq"][heads[k]["pa"]].weight.detach()) for k in plain])
+        t2 = [None] * len(heads)
+        for k, hd in enumerate(heads):      # (before the grouped launch: a split-K direct convolution uses the same workspace)
+            if hd["sb"] != 1:
+                sc, sh = ops.instnorm_stats(t1[k])
+                t2[k] = ops.conv2d(t1[k], self._pk(f"{hd['name']}.{hd['ib']}", hd["cb"]), hd["cb"].bias.detach(), stride=hd["sb"],
+                                   pad_mode=ops.PAD_REFLECT, in_up=2 if hd["spec"]["up_mid"] else 1,
+                                   in_scale=sc, in_shift=sh, in_slope_t=hd["seq"][hd["pa"]].weight.detach())
+        # stage 3: second convolutions
+        second = ops.conv3x3_group([conv_item(f"{heads[k]['name']}.{heads[k]['ib']}", heads[k]["cb"], normed[j],
+                                              in_up=2 if heads[k]["spec"]["up_mid"] else 1, defer_reduce=True)
+                                    for j, k in enumerate(plain)])
+        for j, k in enumerate(plain):
+            t2[k] = second[j]
+        # stage 4: final norms (+ PReLU, x2 upsample, replicated rows) into the trunk's channel slices
+        ops.instnorm_apply_group([dict(x=t2[k], slope_t=hd["seq"][hd["pb"]].weight.detach(), up=2 if hd["spec"]["up_out"] else 1,
+                                       rpad=rpad5 if hd["name"] == "layer5_1" else 0,
+                                       out=trunk[:, hd["i"] * arch.WARP_FEATURE_CH:(hd["i"] + 1) * arch.WARP_FEATURE_CH],
+                                       out_batch_stride=bs) for k, hd in enumerate(heads)])
         x = trunk
         for b in range(arch.WARP_NUM_RESBLOCKS):
             blk = self.layer[b]
@@ -366,7 +387,7 @@ class WarpNet(nn.Module):
         if any(v is None for v in versions) or any(v is None for _, v in pfp):
             return compute()        # inference tensors: nothing to key a change on
         fp = (pfp, regime, ops.conv_algo(), ops.direct_layers(), ops.fuse_reduce(), ops.autotune_enabled(),
-              ops.batch_plan_enabled())
+              ops.batch_plan_enabled(), ops.group_heads())
         memo = getattr(self, "_exemplar_memo", None)
         if (memo is not None and memo[1] == fp and len(memo[0]) == len(key_tensors)
                 and all(a is b and va == vb for (a, va), b, vb in zip(memo[0], key_tensors, versions))):

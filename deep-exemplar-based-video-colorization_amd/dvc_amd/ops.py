@@ -10,7 +10,7 @@ import sys
 import torch
 
 from . import _lib
-from ._lib import DvcConvDesc
+from ._lib import DvcConvDesc, DvcConvGroupItem, DvcInstNormItem
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY, ACT_TANH128 = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -19,6 +19,11 @@ EPS64 = sys.float_info.epsilon  # the reference adds float64 epsilon to fp32 nor
 
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _pv(t):
+    """Raw address for a ctypes structure field (None -> NULL)."""
+    return None if t is None else t.data_ptr()
 
 
 # The launch thread issues ~150 kernels per frame and is within 10-15 % of being the bottleneck of the clip driver
@@ -253,9 +258,13 @@ class ConvPartials:
     [S][N][C][H*W] sitting in the stream's convolution workspace, with the bias / activation still to be applied.  Valid
     until the next convolution on the same stream reuses the workspace; the one consumer is instnorm_apply."""
 
-    def __init__(self, ws, S, shape, bias, act, act_slope, act_slope_t, generation, device):
+    def __init__(self, ws, S, shape, bias, act, act_slope, act_slope_t, generation, device, offset=0):
         self.ws, self.S, self.shape, self.bias = ws, S, tuple(shape), bias
         self.act, self.act_slope, self.act_slope_t, self.generation, self.device = act, act_slope, act_slope_t, generation, device
+        self.offset = int(offset)       # bytes into the workspace (conv3x3_group: several layers' partial sums side by side)
+
+    def data_ptr(self):
+        return self.ws.data_ptr() + self.offset
 
     def check_live(self):
         if self.generation != _conv_ws_generation.get(self.ws.data_ptr()):
@@ -486,11 +495,9 @@ def _wino_rule(N, Cin, Cout, OH, OW, dil):
     # measured on the MI355X (profiles/r02_conv_algo_sweep.txt): with the two-workgroups-per-CU shape Winograd is faster than
     # or level with the direct engine on every eligible layer of the network down to the 13x24 feature maps
     # (per image, never a function of the batch size: a batch must run the kernels its images would run alone)
-    # r03 sweep (profiles/r03_conv_algo_sweep.txt): the one eligible layer where the direct engine wins is WarpNet's 128 -> 64
-    # at 54x96 (21.9 vs 22.5 us: a single 64-channel block of a 0.76-GFLOP layer leaves the Winograd kernel's position-split
-    # workgroups nothing to amortise their prologue over)
-    if Cout == 64 and Cin == 128 and dil == 1 and OH * OW <= 54 * 96:
-        return False
+    # (r03 sweep: WarpNet's 128 -> 64 at 54x96 is the one eligible layer where the direct engine is level, 21.9 vs 22.5 us as a
+    # launch of its own; since r06 it runs inside the grouped launch of the heads' second convolutions, conv3x3_group, which
+    # takes Winograd layers only)
     return OH * OW >= 13 * 24
 
 
@@ -512,6 +519,142 @@ def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub
     return conv2d(x, packs("direct"), bias, dil=dil, pad=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, act=act,
                   act_slope=act_slope, act_slope_t=act_slope_t, residual=residual, out=out,
                   out_batch_stride=out_batch_stride)
+
+
+# ---- independent layers as one launch (r06: WarpNet's four heads).  DVC_GROUP_HEADS=0: one launch per layer (A/B; results are
+# bit-identical either way — every item keeps the plan and the kernel body it has alone)
+_group_heads = _os.environ.get("DVC_GROUP_HEADS", "1") != "0"
+
+
+def group_heads():
+    return _group_heads
+
+
+def set_group_heads(flag=True):
+    global _group_heads
+    _group_heads = bool(flag)
+
+
+def conv3x3_group(items):
+    """`items`: list of dicts with the arguments of conv3x3 (x, weight, packs, bias + keywords) for INDEPENDENT layers.  Returns
+    the list of their results (tensors, or ConvPartials where `defer_reduce` applies), each bit-identical to its own conv3x3
+    call.  One launch for all of them when grouping is on and every item goes to the Winograd engine
+    (dvc_conv2d_winograd_group); otherwise the per-layer calls, in order."""
+    def single(it):
+        kw = {k: v for k, v in it.items() if k not in ("x", "weight", "packs", "bias")}
+        return conv3x3(it["x"], it["weight"], it["packs"], it["bias"], **kw)
+
+    n = len(items)
+    ok = _group_heads and 2 <= n <= 4
+    if ok:
+        for it in items:
+            N, Cin, H, W = it["x"].shape
+            dil = it.get("dil", 1)
+            if (it.get("out") is not None or it.get("residual") is not None or
+                    not winograd_selected(N, Cin, H, W, it["weight"].shape[0], dil=dil, pad=dil, in_up=it.get("in_up", 1),
+                                          in_sub=it.get("in_sub", 1), layer=it.get("layer"))):
+                ok = False
+    if not ok:
+        return [single(it) for it in items]
+    lib = _lib.load()
+    dev = items[0]["x"].device
+    ws = _workspace(dev, CONV_WORKSPACE_BYTES, "conv")
+    arr = (DvcConvGroupItem * n)()
+    meta = []
+    off = 0
+    for i, it in enumerate(items):
+        x, bias = it["x"], it["bias"]
+        u = it["packs"]("winograd")
+        act_slope_t = it.get("act_slope_t")
+        for t, nm in ((x, "x"), (u, "u_packed"), (bias, "bias"), (act_slope_t, "act_slope")):
+            _need(t, nm)
+        N, Cin, H, W = x.shape
+        Cout = u.shape[0] * 32
+        dil, in_up, in_sub = it.get("dil", 1), it.get("in_up", 1), it.get("in_sub", 1)
+        act, act_slope = it.get("act", ACT_NONE), float(it.get("act_slope", 0.0))
+        OH, OW = conv_out_hw(H, W, 3, 1, dil, dil, in_up, in_sub)
+        d = DvcConvDesc(N, Cin, H, W, Cout, 3, 1, dil, dil, it.get("pad_mode", PAD_ZERO), in_up, in_sub, act, act_slope, 0, -1, 0,
+                        0, 0, 0, _plan_flags(N))
+        if layer_record is not None:
+            layer_record.append(dict(layer=it.get("layer"), Cin=Cin, Cout=Cout, H=H, W=W, dil=dil, in_up=in_up, in_sub=in_sub,
+                                     eligible=True))
+        if conv_record is not None:
+            conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=3, stride=1, dil=dil, pad=dil,
+                                    pad_mode=it.get("pad_mode", PAD_ZERO), in_up=in_up, in_sub=in_sub, affine=False, in_prelu=False,
+                                    residual=False, act=act, algo="winograd"))
+        # the split this layer gets ALONE (whole workspace): the grouped launch must reproduce it from this item's share
+        sp, ipl = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.check(lib.dvc_conv2d_winograd_split(ctypes.byref(d), ws.numel(), ctypes.byref(sp), ctypes.byref(ipl)),
+                   "dvc_conv2d_winograd_split")
+        S = sp.value
+        need = (S * N * Cout * OH * OW * 4 + 255) // 256 * 256 if S > 1 else 0
+        room = ws.numel() - off
+        sp2, ipl2 = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.check(lib.dvc_conv2d_winograd_split(ctypes.byref(d), max(room, 0), ctypes.byref(sp2), ctypes.byref(ipl2)),
+                   "dvc_conv2d_winograd_split")
+        if need > room or sp2.value != S or ipl.value < N or ipl2.value < N:
+            return [single(it_) for it_ in items]        # (the workspace cannot hold the items' partial sums side by side)
+        defer = (it.get("defer_reduce", False) and _fuse_reduce and S > 1 and OH * OW <= 16384
+                 and act in (ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY))
+        if defer:
+            d.flags |= DEFER_REDUCE
+        out = None if defer else torch.empty((N, Cout, OH, OW), device=dev, dtype=torch.float32)
+        a = arr[i]
+        a.d = d
+        a.x, a.u_packed, a.bias, a.act_slope_ptr, a.residual = x.data_ptr(), u.data_ptr(), _pv(bias), _pv(act_slope_t), None
+        a.y = ws.data_ptr() + off if out is None else out.data_ptr()
+        a.workspace, a.workspace_bytes = ws.data_ptr() + off, room
+        meta.append((out, S, (N, Cout, OH, OW), bias, act, act_slope, act_slope_t, off, u))
+        off += need
+    generation = _bump_generation(ws)
+    _lib.check(lib.dvc_conv2d_winograd_group(arr, n, _stream()), "dvc_conv2d_winograd_group")
+    return [out if out is not None else ConvPartials(ws, S, shape, bias, act, act_slope, act_slope_t, generation, dev, offset=o)
+            for (out, S, shape, bias, act, act_slope, act_slope_t, o, _u) in meta]
+
+
+def instnorm_apply_group(items):
+    """`items`: list of dicts {x: tensor | ConvPartials, + the keywords of instnorm_apply except `second`} for INDEPENDENT
+    norms.  Returns the list of outputs, bit-identical to the per-item instnorm_apply calls; one launch when grouping is on."""
+    def single(it):
+        kw = {k: v for k, v in it.items() if k != "x"}
+        return instnorm_apply(it["x"], **kw)
+
+    n = len(items)
+    if not (_group_heads and 2 <= n <= 4):
+        return [single(it) for it in items]
+    lib = _lib.load()
+    arr = (DvcInstNormItem * n)()
+    outs = []
+    for i, it in enumerate(items):
+        x = it["x"]
+        part = x if isinstance(x, ConvPartials) else None
+        residual, slope_t, chan_scale = it.get("residual"), it.get("slope_t"), it.get("chan_scale")
+        up, sub, rpad = it.get("up", 1), it.get("sub", 1), it.get("rpad", 0)
+        if part is not None:
+            part.check_live()
+        for t, nm in ((None if part is not None else x, "x"), (chan_scale, "chan_scale"), (residual, "residual"), (slope_t, "slope")):
+            _need(t, nm)
+        N, C, H, W = part.shape if part is not None else x.shape
+        dev = part.device if part is not None else x.device
+        VH, VW = ((H + 1) // 2, (W + 1) // 2) if sub == 2 else (H * up, W * up)
+        out = it.get("out")
+        if out is None:
+            out = torch.empty((N, C, VH + 2 * rpad, VW), device=dev, dtype=torch.float32)
+        a = arr[i]
+        a.x = part.data_ptr() if part is not None else x.data_ptr()
+        a.S = part.S if part is not None else 0
+        a.bias = _pv(part.bias) if part is not None else None
+        a.act = part.act if part is not None else ACT_NONE
+        a.act_slope = part.act_slope if part is not None else 0.0
+        a.act_slope_ptr = _pv(part.act_slope_t) if part is not None else None
+        a.residual, a.slope_ptr, a.chan_scale = _pv(residual), _pv(slope_t), _pv(chan_scale)
+        a.eps = float(it.get("eps", 1e-5))
+        a.N, a.C, a.H, a.W, a.up, a.sub, a.rpad = N, C, H, W, up, sub, rpad
+        a.x_batch_stride, a.res_batch_stride, a.y_batch_stride = 0, 0, it.get("out_batch_stride", 0)
+        a.y = out.data_ptr()
+        outs.append(out)
+    _lib.check(lib.dvc_instnorm_apply_group(arr, n, _stream()), "dvc_instnorm_apply_group")
+    return outs
 
 
 if _autotune:
@@ -641,7 +784,7 @@ def instnorm_apply(x, *, eps=1e-5, chan_scale=None, residual=None, slope_t=None,
         y2 = torch.empty((N, C, (H + 1) // 2, (W + 1) // 2) if sub2 == 2 else (N, C, H, W), device=dev,
                          dtype=torch.float32)
     if part is not None:
-        _lib.check(lib.dvc_instnorm_apply_partials(ctypes.c_void_p(part.ws.data_ptr()), part.S, _p(part.bias), part.act,
+        _lib.check(lib.dvc_instnorm_apply_partials(ctypes.c_void_p(part.data_ptr()), part.S, _p(part.bias), part.act,
                                                    part.act_slope, _p(part.act_slope_t), _p(residual), _p(slope_t),
                                                    _p(chan_scale), float(eps), N, C, H, W, up, sub, rpad, 0, out_batch_stride,
                                                    _p(out), None, None, _p(cs2), sub2, _p(y2), _stream()),

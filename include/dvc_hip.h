@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 15
+#define DVC_ABI_VERSION 16
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -164,6 +164,26 @@ int dvc_conv2d_winograd_dual(const DvcConvDesc* dA, const DvcConvDesc* dB, const
                              const float* act_slope_ptr /* device scalar or NULL */, float* y,
                              void* workspace /* or NULL */, size_t workspace_bytes, dvcStream stream);
 
+/* r06 — several INDEPENDENT 3x3 layers in ONE launch: the first (and the second) convolutions of WarpNet's four heads
+ * (models/NonlocalNet.py:364-410; NonlocalNet.py:451-458 runs the heads on four different VGG taps, nothing connects them).
+ * Item i is exactly dvc_conv2d_winograd(&d, x, u_packed, bias, act_slope_ptr, residual, y, workspace, workspace_bytes): the
+ * same plan, the same kernel body, the same (deferred or launched) split-K reduce — results are bit-identical to the per-item
+ * calls.  The items' workgroups form one grid when every item gets the 64-channel x 32-tile workgroup shape and a single
+ * launch (every head layer at the path's sizes does); otherwise the call degrades to one launch per item.  The items must not
+ * depend on each other; outputs and workspaces must be disjoint.  1 .. 4 items. */
+typedef struct DvcConvGroupItem {
+    DvcConvDesc d;
+    const float* x;
+    const float* u_packed;
+    const float* bias;            /* or NULL */
+    const float* act_slope_ptr;   /* or NULL */
+    const float* residual;        /* or NULL */
+    float* y;
+    void* workspace;              /* this item's own split-K scratch (may be NULL: no split) */
+    size_t workspace_bytes;
+} DvcConvGroupItem;
+int dvc_conv2d_winograd_group(const DvcConvGroupItem* items, int32_t n_items, dvcStream stream);
+
 /* conv 1x1 with tiny Cout (<= 4) + optional tanh*128: ColorVidNet.conv10_ab, ColorVidNet.py:142-144.
  * w is the unpacked [Cout][Cin] matrix. */
 int dvc_conv1x1_small(const float* x, const float* w, const float* bias, int32_t N, int32_t Cin,
@@ -214,6 +234,28 @@ int dvc_instnorm_apply_partials(const float* part, int32_t S, const float* bias,
                                 int32_t sub, int32_t rpad, int64_t res_batch_stride, int64_t y_batch_stride, float* y,
                                 float* scale_out, float* shift_out, const float* chan_scale2, int32_t sub2, float* y2,
                                 dvcStream stream);
+
+/* r06 — several INDEPENDENT InstanceNorm launches as one: the norms of WarpNet's four heads
+ * (models/NonlocalNet.py:364-410, run side by side by NonlocalNet.py:451-458).  Item i is dvc_instnorm_apply (S == 0: `x` is
+ * the tensor, x_batch_stride elements per image, 0 => C*H*W) or dvc_instnorm_apply_partials (S >= 1: `x` is the [S][N][C][H*W]
+ * partial sums, with bias / act / act_slope / act_slope_ptr; H*W <= 16384) without the second output; 1 .. 4 items.
+ * Bit-identical to the per-item calls. */
+typedef struct DvcInstNormItem {
+    const float* x;
+    int32_t S;
+    const float* bias;            /* S >= 1 only, [C] or NULL */
+    int32_t act;                  /* S >= 1 only, DVC_ACT_* of the convolution that left the partial sums */
+    float act_slope;
+    const float* act_slope_ptr;   /* or NULL */
+    const float* residual;        /* or NULL */
+    const float* slope_ptr;       /* PReLU slope of the norm's own activation, or NULL */
+    const float* chan_scale;      /* [C] or NULL */
+    float eps;
+    int32_t N, C, H, W, up, sub, rpad;
+    int64_t x_batch_stride, res_batch_stride, y_batch_stride;   /* elements; 0 => dense */
+    float* y;
+} DvcInstNormItem;
+int dvc_instnorm_apply_group(const DvcInstNormItem* items, int32_t n_items, dvcStream stream);
 
 /* nn.MaxPool2d(2,2) floor mode, NonlocalNet.py:237-255. planes = N*C. */
 int dvc_maxpool2x2(const float* x, int32_t planes, int32_t H, int32_t W, float* y, dvcStream stream);

@@ -149,6 +149,58 @@ def test_warpnet_stages_identical_inputs(nets, weights, H, W):
         assert agree[safe].float().mean().item() > 0.995
 
 
+@pytest.mark.parametrize("H,W,N", [(216, 384, 1), (48, 80, 2), (40, 64, 1), (432, 768, 1)])
+def test_warpnet_heads_grouped_launches_are_bit_identical(nets, weights, H, W, N):
+    """r06: the four heads advance stage by stage, each stage ONE launch over the independent layers
+    (dvc_conv2d_winograd_group / dvc_instnorm_apply_group).  Every item keeps the plan and the kernel body it has as a launch
+    of its own, so heads + trunk must come out bit-identical with DVC_GROUP_HEADS on and off — at the path's size, a batch, the
+    replicate-pad geometry (40x64) and configs[3]'s size; and the grouped form really is fewer launches."""
+    from dvc_amd import _lib, ops, synth
+    warp = nets[1]
+    sd_v = weights[0]
+    with torch.no_grad():
+        nA = [torch.cat([t] + [_norm_feats(sd_v, synth.synth_lab(1000 + k, H, W))[j] for k in range(1, N)])
+              for j, t in enumerate(_norm_feats(sd_v, synth.synth_lab(1000, H, W)))]
+    nA = [t.cuda() for t in nA]
+    lib = _lib.load()
+    calls = {}
+
+    class Spy:
+        def __init__(self, name):
+            self.fn, self.name = getattr(lib, name), name
+
+        def __call__(self, *a):
+            calls[self.name] = calls.get(self.name, 0) + 1
+            return self.fn(*a)
+    names = ["dvc_conv2d_winograd_group", "dvc_instnorm_apply_group", "dvc_conv2d_winograd", "dvc_instnorm_apply",
+             "dvc_instnorm_apply_partials", "dvc_conv2d"]
+
+    def run(flag):
+        calls.clear()
+        ops.set_group_heads(flag)
+        spies = {}
+        try:
+            for nme in names:
+                spies[nme] = getattr(lib, nme)
+                setattr(lib, nme, Spy(nme))
+            out = warp.features(*nA)
+            torch.cuda.synchronize()
+        finally:
+            for nme, fn in spies.items():
+                setattr(lib, nme, fn)
+            ops.set_group_heads(True)
+        return out, dict(calls)
+    warp.prepare()
+    grouped, cg = run(True)
+    single, cs = run(False)
+    assert torch.equal(grouped, single), (grouped - single).abs().max().item()
+    assert torch.isfinite(grouped).all()
+    n_g, n_s = sum(cg.values()), sum(cs.values())
+    report(f"warp.features {H}x{W} N={N}: host calls grouped {cg} = {n_g}, per layer {cs} = {n_s}")
+    assert cg.get("dvc_conv2d_winograd_group", 0) == 2 and cg.get("dvc_instnorm_apply_group", 0) == 2
+    assert n_g <= n_s - 9
+
+
 @pytest.mark.parametrize("seed", [1000, 1001, 1002, 1003])
 def test_correlation_on_real_features_self_consistent(nets, weights, seed):
     """For several frames: (a) the kernel's argmax / sim / gathered colour agree with an fp64 evaluation

@@ -379,6 +379,54 @@ def test_conv2d_winograd_dual(ops, N, CA, CB, Cout, H, W, upA, upB, act):
         ops.conv2d_winograd_dual(xA.cuda(), xB.cuda()[:, :, :-2].contiguous(), u, b, in_upA=upA, in_upB=upB)
 
 
+def test_conv2d_winograd_group_and_instnorm_group_match_the_single_calls(ops):
+    """dvc_conv2d_winograd_group / dvc_instnorm_apply_group (r06): independent layers of different sizes, splits and tile-block
+    shapes in one launch; tensors and deferred partial sums side by side in the workspace; every result bit-identical to the
+    layer's own launch and within fp32 rounding of a float64 convolution."""
+    g = torch.Generator().manual_seed(77)
+    shapes = [(1, 128, 128, 54, 96, 1), (1, 256, 128, 27, 48, 1), (1, 512, 256, 13, 24, 2), (2, 256, 64, 13, 24, 1)]
+    items, refs = [], []
+    for (N, Cin, Cout, H, W, up) in shapes:
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        wc = w.cuda()
+        packs = (lambda wc_: (lambda kind: ops.pack_winograd_weight(wc_) if kind == "winograd" else ops.pack_conv_weight(wc_)))(wc)
+        items.append(dict(x=x.cuda(), weight=wc, packs=packs, bias=b.cuda(), pad_mode=ops.PAD_REFLECT, in_up=up, defer_reduce=True))
+        refs.append(ref_conv(x, w, b, 3, 1, 1, 1, 1, up, 1, None, None, None, None, 0, 0.0))
+    slope = torch.full((1,), 0.25).cuda()
+
+    def run(flag):
+        ops.set_group_heads(flag)
+        try:
+            t = ops.conv3x3_group(items)
+            kinds = [type(v).__name__ for v in t]
+            y = ops.instnorm_apply_group([dict(x=v, slope_t=slope, up=2 if i == 2 else 1, rpad=1 if i == 3 else 0) for i, v in enumerate(t)])
+            torch.cuda.synchronize()
+            return y, kinds
+        finally:
+            ops.set_group_heads(True)
+    yg, kg = run(True)
+    ys, ks = run(False)
+    assert kg == ks and "ConvPartials" in kg, (kg, ks)        # (at least one layer is split: its partial sums stay in the workspace)
+    for i, (a, b_) in enumerate(zip(yg, ys)):
+        assert torch.equal(a, b_), (i, (a - b_).abs().max().item())
+        r = refs[i]
+        m, v = r.mean((2, 3), keepdim=True), r.var((2, 3), unbiased=False, keepdim=True)
+        n = (r - m) / (v + 1e-5).sqrt()
+        n = torch.where(n >= 0, n, n * 0.25)
+        if i == 2:
+            n = F.interpolate(n, scale_factor=2, mode="nearest")
+        if i == 3:
+            n = F.pad(n, (0, 0, 1, 1), mode="replicate")
+        assert a.shape == n.shape
+        e = (a.double().cpu() - n).abs().max().item()
+        assert e < 5e-5, (i, e)
+    # one item, five items, an item that is not a Winograd layer: the per-layer calls, same results
+    one = ops.conv3x3_group(items[:1])
+    assert len(one) == 1
+
+
 @pytest.mark.parametrize("B,K,M,H,W,split_k", [(4, 256, 320, 13, 24, 0), (3, 512, 1344, 27, 48, 0), (2, 96, 64, 9, 11, 2), (1, 64, 128, 8, 8, 0)])
 def test_conv2d_per_image_filters_is_a_batched_gemm(ops, B, K, M, H, W, split_k):
     """DvcConvDesc.w_batch_stride (r04): a 1x1 "convolution" whose filters differ per image is the batched GEMM
