@@ -737,9 +737,7 @@ extern "C" int dvc_conv2d_winograd_group(const DvcConvGroupItem* items, int32_t 
     for (int i = 0; i < n_items; ++i) {
         const DvcConvGroupItem& it = items[i];
         DVC_REQUIRE(it.x && it.u_packed && it.y, "dvc_conv2d_winograd_group: null argument in item %d", i);
-        for (int j = 0; j < i; ++j)
-            DVC_REQUIRE(it.y != items[j].y && (!it.workspace || it.workspace != items[j].workspace),
-                        "dvc_conv2d_winograd_group: items %d and %d share an output or a workspace", j, i);
+        for (int j = 0; j < i; ++j) DVC_REQUIRE(it.y != items[j].y, "dvc_conv2d_winograd_group: items %d and %d share an output", j, i);
         int m = -1, grp = 0;
         if (int rc = wino_setup(&it.d, nullptr, it.x, nullptr, it.u_packed, it.bias, it.act_slope_ptr, it.residual, it.y, it.workspace,
                                 it.workspace_bytes, nullptr, 0, tmp[i], &m, &trs[i], &grp))
@@ -748,6 +746,9 @@ extern "C" int dvc_conv2d_winograd_group(const DvcConvGroupItem* items, int32_t 
         dvc_conv2d_out_hw(&it.d, &oh, &ow);
         OHs[i] = oh; OWs[i] = ow;
         if (m != 2 || grp < it.d.N) together = false;
+        for (int j = 0; j < i; ++j)     // (only split items touch their workspace)
+            DVC_REQUIRE(!(tmp[i].k.split > 1 && tmp[j].k.split > 1 && tmp[i].k.part == tmp[j].k.part),
+                        "dvc_conv2d_winograd_group: the split items %d and %d share a workspace", j, i);
         order[i] = i;
     }
     if (!together) {

@@ -273,10 +273,13 @@ class ConvPartials:
 
 
 def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1, act=ACT_NONE, act_slope=0.0,
-                    act_slope_t=None, residual=None, out=None, out_batch_stride=0, cfg=-1, split_k=0, defer_reduce=False):
+                    act_slope_t=None, residual=None, out=None, out_batch_stride=0, cfg=-1, split_k=0, defer_reduce=False,
+                    ws_tag="conv"):
     """dvc_conv2d_winograd: 3x3, stride 1, pad == dil.  u_packed from pack_winograd_weight.
     defer_reduce=True: if the library splits this layer over input channels, skip the reduce launch and return the
-    ConvPartials for instnorm_apply to sum (otherwise the ordinary output tensor)."""
+    ConvPartials for instnorm_apply to sum (otherwise the ordinary output tensor).
+    `ws_tag`: which of the stream's convolution workspaces to use (conv3x3_group's per-layer fall-back keeps the deferred
+    partial sums of several layers alive at once)."""
     lib = _lib.load()
     for t, nm in ((x, "x"), (u_packed, "u_packed"), (bias, "bias"), (act_slope_t, "act_slope"), (residual, "residual")):
         _need(t, nm)
@@ -294,7 +297,7 @@ def conv2d_winograd(x, u_packed, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_
         conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=3, stride=1, dil=dil, pad=dil, pad_mode=pad_mode,
                                 in_up=in_up, in_sub=in_sub, affine=False, in_prelu=False, residual=residual is not None,
                                 act=act, algo="winograd"))
-    ws = _workspace(x.device, CONV_WORKSPACE_BYTES, "conv")
+    ws = _workspace(x.device, CONV_WORKSPACE_BYTES, ws_tag)
     generation = _bump_generation(ws)
     S = 1
     if defer_reduce and residual is None and OH * OW <= 16384 and act in (ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY):
@@ -502,7 +505,7 @@ def _wino_rule(N, Cin, Cout, OH, OW, dil):
 
 
 def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1, act=ACT_NONE, act_slope=0.0,
-            act_slope_t=None, residual=None, out=None, out_batch_stride=0, defer_reduce=False, layer=None):
+            act_slope_t=None, residual=None, out=None, out_batch_stride=0, defer_reduce=False, layer=None, ws_tag="conv"):
     """A 3x3 stride-1 pad == dil layer through whichever engine the algorithm choice selects.  `packs(kind)` returns
     the packed weight for kind "direct" ([Cin][9][Cout]) or "winograd" (U = G g G^T), normally from a _PackCache.
     `layer`: the layer's name in the error-aware engine map (direct_layers)."""
@@ -515,7 +518,7 @@ def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub
     if winograd_selected(N, Cin, H, W, Cout, dil=dil, pad=dil, in_up=in_up, in_sub=in_sub, layer=layer):
         return conv2d_winograd(x, packs("winograd"), bias, dil=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub,
                                act=act, act_slope=act_slope, act_slope_t=act_slope_t, residual=residual, out=out,
-                               out_batch_stride=out_batch_stride, defer_reduce=defer_reduce and _fuse_reduce)
+                               out_batch_stride=out_batch_stride, defer_reduce=defer_reduce and _fuse_reduce, ws_tag=ws_tag)
     return conv2d(x, packs("direct"), bias, dil=dil, pad=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, act=act,
                   act_slope=act_slope, act_slope_t=act_slope_t, residual=residual, out=out,
                   out_batch_stride=out_batch_stride)
@@ -540,9 +543,11 @@ def conv3x3_group(items):
     the list of their results (tensors, or ConvPartials where `defer_reduce` applies), each bit-identical to its own conv3x3
     call.  One launch for all of them when grouping is on and every item goes to the Winograd engine
     (dvc_conv2d_winograd_group); otherwise the per-layer calls, in order."""
-    def single(it):
+    def single(it, i=0):
+        # (per-layer launches: the items' deferred partial sums must all be alive when the caller's next stage consumes them,
+        # so every item but the first gets a convolution workspace of its own — same size, hence the same plan)
         kw = {k: v for k, v in it.items() if k not in ("x", "weight", "packs", "bias")}
-        return conv3x3(it["x"], it["weight"], it["packs"], it["bias"], **kw)
+        return conv3x3(it["x"], it["weight"], it["packs"], it["bias"], ws_tag="conv" if i == 0 else f"conv.g{i}", **kw)
 
     n = len(items)
     ok = _group_heads and 2 <= n <= 4
@@ -555,7 +560,7 @@ def conv3x3_group(items):
                                           in_sub=it.get("in_sub", 1), layer=it.get("layer"))):
                 ok = False
     if not ok:
-        return [single(it) for it in items]
+        return [single(it, i) for i, it in enumerate(items)]
     lib = _lib.load()
     dev = items[0]["x"].device
     ws = _workspace(dev, CONV_WORKSPACE_BYTES, "conv")
@@ -593,7 +598,7 @@ def conv3x3_group(items):
         _lib.check(lib.dvc_conv2d_winograd_split(ctypes.byref(d), max(room, 0), ctypes.byref(sp2), ctypes.byref(ipl2)),
                    "dvc_conv2d_winograd_split")
         if need > room or sp2.value != S or ipl.value < N or ipl2.value < N:
-            return [single(it_) for it_ in items]        # (the workspace cannot hold the items' partial sums side by side)
+            return [single(it_, j) for j, it_ in enumerate(items)]   # (the workspace cannot hold the items' partial sums side by side)
         defer = (it.get("defer_reduce", False) and _fuse_reduce and S > 1 and OH * OW <= 16384
                  and act in (ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY))
         if defer:

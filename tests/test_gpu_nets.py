@@ -197,8 +197,9 @@ def test_warpnet_heads_grouped_launches_are_bit_identical(nets, weights, H, W, N
     assert torch.isfinite(grouped).all()
     n_g, n_s = sum(cg.values()), sum(cs.values())
     report(f"warp.features {H}x{W} N={N}: host calls grouped {cg} = {n_g}, per layer {cs} = {n_s}")
-    assert cg.get("dvc_conv2d_winograd_group", 0) == 2 and cg.get("dvc_instnorm_apply_group", 0) == 2
-    assert n_g <= n_s - 9
+    assert cg.get("dvc_instnorm_apply_group", 0) == 2 and n_g < n_s
+    if H >= 216:        # (smaller maps: the heads' layers are below the Winograd rule's 13x24 and keep their direct launches)
+        assert cg.get("dvc_conv2d_winograd_group", 0) == 2 and n_g <= n_s - 9
 
 
 @pytest.mark.parametrize("seed", [1000, 1001, 1002, 1003])
