@@ -1,7 +1,7 @@
 // Winograd F(2x2, 3x3) form of the 3x3 stride-1 convolutions, on the gfx950 fp32 matrix cores.
 //
 // Why: the 3x3 layers carry 97 % of the path's FLOPs and the direct implicit GEMM (conv_kernel.h, conv_sk_kernel.h) is
-// bound by the fp32 MFMA issue rate plus per-launch costs (DESIGN.md 4.2b).  The minimal-filtering form needs 16 instead
+// bound by the fp32 MFMA issue rate plus per-launch costs (DESIGN.md 4.2).  The minimal-filtering form needs 16 instead
 // of 36 multiplies per 2x2 output tile and input channel: 2.25x fewer MFMAs for the same result up to fp32 rounding
 // (measured 2.3x the rounding error of the direct sum against an fp64 convolution, i.e. ~6e-7 of the output range —
 // the same algorithm cuDNN picks for these shapes under the reference's `cudnn.benchmark = True`, test.py:140).
