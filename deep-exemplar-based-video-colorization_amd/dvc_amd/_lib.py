@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DVC_DEBUG_LIB=1 (tools/ only) loads the -DDVC_DEBUG build, the only one that carries the dvc_debug_* hooks
 DEBUG_BUILD = os.environ.get("DVC_DEBUG_LIB", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "libdvc_hip_debug.so" if DEBUG_BUILD else "libdvc_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -65,6 +65,9 @@ SIGNATURES = {
                                                 ctypes.c_size_t, _VP]),
     "dvc_conv2d_winograd_dual": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP,
                                                 _VP, _VP, ctypes.c_size_t, _VP]),
+    "dvc_conv2d_ws_eligible": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc)]),
+    "dvc_conv2d_ws_pack_weight": (ctypes.c_int, [_VP, c_i32, c_i32, _VP, _VP]),
+    "dvc_conv2d_ws": (ctypes.c_int, [ctypes.POINTER(DvcConvDesc), _VP, _VP, _VP, _VP, _VP, _VP]),
     "dvc_conv2d_winograd_group": (ctypes.c_int, [ctypes.POINTER(DvcConvGroupItem), c_i32, _VP]),
     "dvc_instnorm_apply_group": (ctypes.c_int, [ctypes.POINTER(DvcInstNormItem), c_i32, _VP]),
     "dvc_conv1x1_small": (ctypes.c_int, [_VP, _VP, _VP, c_i32, c_i32, c_i32, c_i32, c_i32, _VP, _VP]),

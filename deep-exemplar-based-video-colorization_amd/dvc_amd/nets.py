@@ -101,6 +101,8 @@ def _packs(cache, key, weight):
     def get(kind):
         if kind == "winograd":
             return cache.get(key + ":wino", weight, ops.pack_winograd_weight)
+        if kind == "ws":
+            return cache.get(key + ":ws", weight, ops.pack_ws_weight)
         return cache.get(key, weight, ops.pack_conv_weight)
     return get
 
@@ -112,6 +114,8 @@ def _prepack(cache, key, conv):
     co, ci, kh, kw = conv.weight.shape
     if ops.conv_algo() != "direct" and conv.stride[0] == 1 and ops.winograd_eligible(ci, co, kh):
         get("winograd")
+    if ops.ws_conv_enabled() and conv.stride[0] == 1 and kh == 3 and ops.ws_eligible(ci, co):
+        get("ws")
 
 
 def _norm_in_place(t, **kw):
@@ -387,7 +391,7 @@ class WarpNet(nn.Module):
         if any(v is None for v in versions) or any(v is None for _, v in pfp):
             return compute()        # inference tensors: nothing to key a change on
         fp = (pfp, regime, ops.conv_algo(), ops.direct_layers(), ops.fuse_reduce(), ops.autotune_enabled(),
-              ops.batch_plan_enabled(), ops.group_heads())
+              ops.batch_plan_enabled(), ops.group_heads(), ops.ws_conv_enabled())
         memo = getattr(self, "_exemplar_memo", None)
         if (memo is not None and memo[1] == fp and len(memo[0]) == len(key_tensors)
                 and all(a is b and va == vb for (a, va), b, vb in zip(memo[0], key_tensors, versions))):

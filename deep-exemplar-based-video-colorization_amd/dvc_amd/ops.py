@@ -192,6 +192,55 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
     return out
 
 
+# ---- weights-in-registers direct engine (r06, csrc/conv_ws.hip): the large-map / few-channel 3x3 layers that stay on the direct
+# engine (ColorVidNet conv1_1[2], conv1_2, conv2_1 under the error-aware map).  DVC_WS_CONV=0: the general direct engine (A/B).
+_ws_conv = _os.environ.get("DVC_WS_CONV", "1") != "0"
+
+
+def ws_conv_enabled():
+    return _ws_conv
+
+
+def set_ws_conv(flag=True):
+    global _ws_conv
+    _ws_conv = bool(flag)
+
+
+def ws_eligible(Cin, Cout, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1, act=ACT_NONE):
+    """Geometry the weights-in-registers kernel takes (dvc_conv2d_ws_eligible): 3x3 stride 1 pad 1, zero padding, plain input,
+    32 or 64 input channels, Cout % 64 == 0."""
+    return (Cin in (32, 64) and Cout % 64 == 0 and dil == 1 and pad_mode == PAD_ZERO and in_up == 1 and in_sub == 1
+            and act in (ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY))
+
+
+def pack_ws_weight(w):
+    """[Cout][Cin][3][3] -> the MFMA A-fragment order dvc_conv2d_ws loads (dvc_conv2d_ws_pack_weight), Cout*Cin*9 floats."""
+    lib = _lib.load()
+    w = w.detach().contiguous().float()
+    _need(w, "weight")
+    Cout, Cin = w.shape[0], w.shape[1]
+    u = torch.empty(Cout * Cin * 9, device=w.device, dtype=torch.float32)
+    _lib.check(lib.dvc_conv2d_ws_pack_weight(_p(w), Cout, Cin, _p(u), _stream()), "dvc_conv2d_ws_pack_weight")
+    return u
+
+
+def conv2d_ws(x, u_packed, bias, Cout, *, act=ACT_NONE, act_slope=0.0, act_slope_t=None, out=None, out_batch_stride=0):
+    """dvc_conv2d_ws: 3x3 / stride 1 / pad 1 (zero) with the filters resident in registers; see ws_eligible."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (u_packed, "u_packed"), (bias, "bias"), (act_slope_t, "act_slope")):
+        _need(t, nm)
+    N, Cin, H, W = x.shape
+    assert u_packed.numel() == Cout * Cin * 9, (u_packed.shape, Cout, Cin)
+    if out is None:
+        out = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.float32)
+    d = DvcConvDesc(N, Cin, H, W, Cout, 3, 1, 1, 1, PAD_ZERO, 1, 1, act, float(act_slope), 0, -1, 0, 0, out_batch_stride, 0, 0)
+    if conv_record is not None:
+        conv_record.append(dict(N=N, Cin=Cin, H=H, W=W, Cout=Cout, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_ZERO, in_up=1,
+                                in_sub=1, affine=False, in_prelu=False, residual=False, act=act, algo="direct-ws"))
+    _lib.check(lib.dvc_conv2d_ws(ctypes.byref(d), _p(x), _p(u_packed), _p(bias), _p(act_slope_t), _p(out), _stream()), "dvc_conv2d_ws")
+    return out
+
+
 def pack_winograd_weight(w):
     """[Cout][Cin][3][3] -> the Winograd F(2x2,3x3) transform-domain filters U = G g G^T in the layout
     dvc_conv2d_winograd stages, [Cout/32][Cin][4][32][4] (dvc_winograd_pack_weight: evaluated in double, rounded once)."""
@@ -519,6 +568,9 @@ def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub
         return conv2d_winograd(x, packs("winograd"), bias, dil=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub,
                                act=act, act_slope=act_slope, act_slope_t=act_slope_t, residual=residual, out=out,
                                out_batch_stride=out_batch_stride, defer_reduce=defer_reduce and _fuse_reduce, ws_tag=ws_tag)
+    if _ws_conv and residual is None and ws_eligible(Cin, Cout, dil, pad_mode, in_up, in_sub, act):
+        return conv2d_ws(x, packs("ws"), bias, Cout, act=act, act_slope=act_slope, act_slope_t=act_slope_t, out=out,
+                         out_batch_stride=out_batch_stride)
     return conv2d(x, packs("direct"), bias, dil=dil, pad=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, act=act,
                   act_slope=act_slope, act_slope_t=act_slope_t, residual=residual, out=out,
                   out_batch_stride=out_batch_stride)

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 16
+#define DVC_ABI_VERSION 17
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -163,6 +163,21 @@ int dvc_conv2d_winograd_dual(const DvcConvDesc* dA, const DvcConvDesc* dB, const
                              const float* u_packed_cat, const float* bias /* may be NULL */,
                              const float* act_slope_ptr /* device scalar or NULL */, float* y,
                              void* workspace /* or NULL */, size_t workspace_bytes, dvcStream stream);
+
+/* r06 — weights-in-registers direct convolution (csrc/conv_ws.hip) for the large-map, few-channel 3x3 layers of ColorVidNet's
+ * encoder (models/ColorVidNet.py:98-103: conv1_1[2] 32 -> 64 and conv1_2 64 -> 64 at full frame size, conv2_1 64 -> 128 at half
+ * size): same arithmetic class as dvc_conv2d (exact fp32 products, blocked fp32 accumulation: chains of 8 channels x 9 taps
+ * added to a running total), another decomposition — a wave keeps its 32 x 32 x 9 filter block in 144 VGPRs for the whole
+ * launch and walks down a 32-pixel column strip whose input rows stream through an LDS ring.
+ * Eligible (dvc_conv2d_ws_eligible != 0): ksize 3, stride 1, dil 1, pad 1, zero padding, no up / sub-sampling, no fused input
+ * transform, Cin 32 or 64, Cout % 64 == 0, act NONE / RELU / PRELU / LEAKY; no residual.  `u_packed`: Cout * Cin * 9 floats
+ * written by dvc_conv2d_ws_pack_weight from the module's [Cout][Cin][3][3] weight (fragment order, 16-byte aligned).
+ * x_batch_stride / y_batch_stride of the descriptor are honoured; cfg / split_k / flags are ignored (one plan per geometry,
+ * per image: a batch of N is bit-identical to N calls). */
+int dvc_conv2d_ws_eligible(const DvcConvDesc* d);
+int dvc_conv2d_ws_pack_weight(const float* w, int32_t Cout, int32_t Cin, float* u_packed, dvcStream stream);
+int dvc_conv2d_ws(const DvcConvDesc* d, const float* x, const float* u_packed, const float* bias /* may be NULL */,
+                  const float* act_slope_ptr /* may be NULL */, float* y, dvcStream stream);
 
 /* r06 — several INDEPENDENT 3x3 layers in ONE launch: the first (and the second) convolutions of WarpNet's four heads
  * (models/NonlocalNet.py:364-410; NonlocalNet.py:451-458 runs the heads on four different VGG taps, nothing connects them).

@@ -379,6 +379,62 @@ def test_conv2d_winograd_dual(ops, N, CA, CB, Cout, H, W, upA, upB, act):
         ops.conv2d_winograd_dual(xA.cuda(), xB.cuda()[:, :, :-2].contiguous(), u, b, in_upA=upA, in_upB=upB)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,act,bias", [
+    (1, 64, 64, 216, 384, 1, True), (1, 32, 64, 216, 384, 1, True), (2, 64, 128, 108, 192, 1, True),
+    (1, 64, 64, 13, 37, 0, True), (1, 32, 64, 7, 5, 3, False), (1, 32, 128, 9, 70, 2, True), (3, 64, 64, 1, 1, 1, True),
+    (1, 64, 192, 33, 33, 0, False), (1, 32, 64, 2, 32, 1, True)])
+def test_conv2d_ws_weights_in_registers_engine(ops, N, Cin, Cout, H, W, act, bias):
+    """dvc_conv2d_ws (r06, csrc/conv_ws.hip): the large-map / few-channel 3x3 layers with the filters resident in registers.
+    Against a float64 convolution (the direct engine's tolerance, 2e-5 relative; measured ~1e-6) and against the general direct
+    engine (same products, same 72-term chains, another order of the partial totals: <= 2e-6 of the output range); ragged
+    strips (W not a multiple of 32), odd heights under the two-rows-per-step form, single pixels, batches, every activation,
+    a channel-slice destination; deterministic."""
+    g = torch.Generator().manual_seed(N * 100000 + Cin * 1000 + H * 10 + W)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    slope = torch.full((1,), 0.2)
+    ref = ref_conv(x, w, b, 3, 1, 1, 1, 0, 1, 1, None, None, None, None, act, 0.2)
+    u = ops.pack_ws_weight(w.cuda())
+    kw = dict(act=act, act_slope=0.2, act_slope_t=slope.cuda() if act == 2 else None)
+    got = ops.conv2d_ws(x.cuda(), u, None if b is None else b.cuda(), Cout, **kw)
+    torch.cuda.synchronize()
+    e = relerr(got, ref)
+    gen = ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), None if b is None else b.cuda(), **kw)
+    e2 = ((got - gen).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+    report(f"conv2d_ws {Cin}->{Cout} {H}x{W} N={N} act={act}: rel_err vs fp64 {e:.2e}, vs the general direct engine {e2:.2e}")
+    assert e < 2e-5 and e2 < 2e-6
+    assert torch.equal(ops.conv2d_ws(x.cuda(), u, None if b is None else b.cuda(), Cout, **kw), got)
+    # a batch is bit-identical to single-image calls; the output may be a channel slice of a wider tensor
+    if N > 1:
+        one = ops.conv2d_ws(x[1:2].cuda().contiguous(), u, None if b is None else b.cuda(), Cout, **kw)
+        assert torch.equal(one, got[1:2])
+    wide = torch.full((N, Cout + 32, H, W), 7.0).cuda()
+    ops.conv2d_ws(x.cuda(), u, None if b is None else b.cuda(), Cout, out=wide[:, 32:], out_batch_stride=(Cout + 32) * H * W, **kw)
+    assert torch.equal(wide[:, 32:], got) and bool((wide[:, :32] == 7.0).all())
+
+
+def test_conv3x3_routes_direct_layers_to_the_ws_engine(ops):
+    """ops.conv3x3 under the error-aware map: a named direct layer of an eligible geometry takes dvc_conv2d_ws (DVC_WS_CONV=0:
+    the general engine), everything else is unchanged."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 40, 64, generator=g).cuda()
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).cuda()
+    b = torch.randn(64, generator=g).cuda()
+    packs = lambda kind: {"winograd": ops.pack_winograd_weight, "ws": ops.pack_ws_weight, "direct": ops.pack_conv_weight}[kind](w)   # noqa: E731
+    rec = []
+    ops.conv_record = rec
+    try:
+        a = ops.conv3x3(x, w, packs, b, act=ops.ACT_RELU, layer="cvn.conv1_2")
+        ops.set_ws_conv(False)
+        c = ops.conv3x3(x, w, packs, b, act=ops.ACT_RELU, layer="cvn.conv1_2")
+    finally:
+        ops.set_ws_conv(True)
+        ops.conv_record = None
+    assert [r.get("algo") for r in rec] == ["direct-ws", None]
+    assert (a - c).abs().max().item() < 2e-6 * c.abs().max().item()
+
+
 def test_conv2d_winograd_group_and_instnorm_group_match_the_single_calls(ops):
     """dvc_conv2d_winograd_group / dvc_instnorm_apply_group (r06): independent layers of different sizes, splits and tile-block
     shapes in one launch; tensors and deferred partial sums side by side in the workspace; every result bit-identical to the

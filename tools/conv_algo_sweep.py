@@ -82,6 +82,11 @@ for k, (r, count) in uniq.items():
                                                      in_sub=r["in_sub"], act=r["act"], act_slope=0.2, residual=res)
         yd, yw = cands["direct"](), cands["wino"]()
         err = ((yd - yw).abs().max() / yd.abs().max()).item()
+    ws_ok = (r["ksize"] == 3 and r["stride"] == 1 and r["pad"] == 1 and not r["affine"] and not r["in_prelu"] and not r["residual"]
+             and ops.ws_eligible(r["Cin"], r["Cout"], r["dil"], r["pad_mode"], r["in_up"], r["in_sub"], r["act"]))
+    if ws_ok:       # r06: the weights-in-registers direct engine (csrc/conv_ws.hip)
+        uws = ops.pack_ws_weight(w)
+        cands["ws"] = lambda: ops.conv2d_ws(x, uws, b, r["Cout"], act=r["act"], act_slope=0.2)
     for _ in range(40):
         cands["direct"]()
     best = {kk: float("inf") for kk in cands}
@@ -98,9 +103,9 @@ for k, (r, count) in uniq.items():
     tot["auto"] += count * (tw if sel else td)
     tot["best"] += count * min(td, tw)
     gf_tot += count * gf
-    rows.append(dict(layer=r, count=count, gflop=gf, us_direct=td, us_wino=best.get("wino"), auto_is_wino=bool(sel), rel_diff=err))
+    rows.append(dict(layer=r, count=count, gflop=gf, us_direct=td, us_direct_ws=best.get("ws"), us_wino=best.get("wino"), auto_is_wino=bool(sel), rel_diff=err))
     print(f"x{count} {r['Cin']:4d}->{r['Cout']:4d} k{r['ksize']} s{r['stride']} d{r['dil']} {r['H']:3d}x{r['W']:3d} up{r['in_up']} sub{r['in_sub']} "
-          f"{gf:6.2f} GF: direct {td:6.1f} us" + (f", wino {tw:6.1f} us ({gf / tw * 1e3:5.1f} TF eff), auto={'wino' if sel else 'direct'}, "
+          f"{gf:6.2f} GF: direct {td:6.1f} us" + (f", direct-ws {best['ws']:6.1f} us ({gf / best['ws'] * 1e3:5.1f} TF)" if ws_ok else "") + (f", wino {tw:6.1f} us ({gf / tw * 1e3:5.1f} TF eff), auto={'wino' if sel else 'direct'}, "
                                                    f"|diff|/max = {err:.1e}" if elig else " (not eligible)"), flush=True)
 print(f"per frame, {gf_tot:.1f} GFLOP of convolutions: " + ", ".join(f"{k} {v / 1e3:.3f} ms ({gf_tot / v * 1e3:.1f} TF)" for k, v in tot.items()))
 os.makedirs("gpurun_out", exist_ok=True)
