@@ -1,4 +1,4 @@
-// Weights-in-registers direct convolution (r06): 3x3, stride 1, pad 1 (zero), Cin = 32 / 64, on v_mfma_f32_32x32x2_f32.
+// Weights-in-registers direct convolution (r06): 3x3, stride 1, pad 1 (zero), Cin = 32 / 64 / 128, on v_mfma_f32_32x32x2_f32.
 //
 // Why: the layers of ColorVidNet's encoder that must stay on the direct engine (arch.DIRECT_LAYERS: Winograd's rounding there
 // puts the whole path above the reference's own fp32 error) are large in space and small in channels (32 -> 64 and 64 -> 64 at
@@ -15,7 +15,7 @@
 //   * a row's 32 pixels x 32 output channels are a chain of 144 MFMAs per wave (B fragment = one ds_read_b32 with an immediate
 //     offset per MFMA, two pairs ahead in fixed registers: conv_ws_chain.inc), restarted from zero every 36 (8 channels x 9
 //     taps) and added to a running total — the direct engine's blocked summation, the same chain lengths;
-//   * Cin = 64: two waves split the input channels (KH = 2) and combine their totals through LDS once per row;
+//   * Cin = 64 (128): two (four) waves split the input channels (KH = 2, 4) and combine their totals through LDS once per row;
 //     Cin = 32: one wave holds all of K and the workgroup's second wave pair takes every other row (PS = 2);
 //   * ONE barrier per row step; no filter traffic after the prologue; 2 workgroups per CU (<= 256 VGPRs).
 // fp32 throughout: exact products, fp32 accumulation, chain lengths 72 + a short tree — the direct engine's error class.
@@ -50,15 +50,17 @@ __device__ __forceinline__ float ws_act(float v, int act, float slope) {
     }
 }
 
-// KH: waves that split the 32 * KH input channels; CT: 32-channel output tiles per workgroup; PS: rows per step.  KH * CT * PS = 4.
+// KH: waves that split the 32 * KH input channels; CT: 32-channel output tiles per workgroup; PS: rows per step.
+// KH * CT * PS = 4 waves (two workgroups per CU) or 8 (Cin = 128: KH = 4, CT = 2 — one workgroup per CU): two waves per SIMD either way.
 template <int KH, int CT, int PS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_ws_kernel(ConvWsArgs a) {
+__global__ __launch_bounds__(64 * KH * CT * PS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_ws_kernel(ConvWsArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(KH * CT * PS == 4, "four waves");
+    static_assert(KH * CT * PS == 4 || KH * CT * PS == 8, "four or eight waves");
+    constexpr int NT = 64 * KH * CT * PS;
     constexpr int CIN = 32 * KH;
     constexpr int ROWF = 34;                              // staged floats per channel row (32 pixels + halo)
-    constexpr int EPT = (CIN * ROWF + 255) / 256;         // DMA instructions per thread and row
-    constexpr int SLOT = EPT * 256;                       // floats per ring slot (the tail is padding the DMA zero-fills)
+    constexpr int EPT = (CIN * ROWF + NT - 1) / NT;       // DMA instructions per thread and row
+    constexpr int SLOT = EPT * NT;                        // floats per ring slot (the tail is padding the DMA zero-fills)
     constexpr int R = 2 * PS + 2;                         // ring: PS + 2 rows in use, PS rows in flight
     constexpr int OOB = (int)0x80000000;
     constexpr int XW = (KH - 1) * CT * PS;                // waves that hand a partial total over
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int gofs[EPT];
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
-        const int e = t * 256 + tid;
+        const int e = t * NT + tid;
         const int c = e / ROWF, col = e - c * ROWF;
         const int gx = x0 - 1 + col;
         gofs[t] = (c < CIN && gx >= 0 && gx < a.W) ? (c * HW + gx) * 4 : OOB;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float* dst = ring + slot * SLOT;
 #pragma unroll
         for (int t = 0; t < EPT; ++t)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (WS_AS3 void*)(dst + t * 256 + wave * 64), 4, ok ? gofs[t] : OOB, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (WS_AS3 void*)(dst + t * NT + wave * 64), 4, ok ? gofs[t] : OOB, so, 0, 0);
     };
     // this lane's B operand inside a slot: channel kh * 32 + hi of its pixel (tap column 0)
     const unsigned lanepart = (unsigned)(size_t)(WS_AS3 float*)ring + (unsigned)(((kh * 32 + hi) * ROWF + l31) * 4);
@@ -218,14 +220,14 @@ __global__ __launch_bounds__(256) void conv_ws_pack_kernel(const float* __restri
 extern "C" int dvc_conv2d_ws_eligible(const DvcConvDesc* d) {
     if (!d) return 0;
     return d->ksize == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && d->pad_mode == DVC_PAD_ZERO && d->in_up == 1 &&
-           d->in_sub == 1 && !d->in_prelu && (d->Cin == 32 || d->Cin == 64) && d->Cout % 64 == 0 && d->N > 0 && d->H > 0 &&
+           d->in_sub == 1 && !d->in_prelu && (d->Cin == 32 || d->Cin == 64 || d->Cin == 128) && d->Cout % 64 == 0 && d->N > 0 && d->H > 0 &&
            d->W > 0 && (long)d->Cin * d->H * d->W * 4 < (1L << 31) &&
            (d->act == DVC_ACT_NONE || d->act == DVC_ACT_RELU || d->act == DVC_ACT_PRELU || d->act == DVC_ACT_LEAKY);
 }
 
 extern "C" int dvc_conv2d_ws_pack_weight(const float* w, int32_t Cout, int32_t Cin, float* u_packed, dvcStream stream) {
     DVC_REQUIRE(w && u_packed, "dvc_conv2d_ws_pack_weight: null argument");
-    DVC_REQUIRE(Cout > 0 && Cout % 32 == 0 && (Cin == 32 || Cin == 64), "dvc_conv2d_ws_pack_weight: needs Cout %% 32 == 0 and Cin 32 or 64 (got %d, %d)",
+    DVC_REQUIRE(Cout > 0 && Cout % 32 == 0 && (Cin == 32 || Cin == 64 || Cin == 128), "dvc_conv2d_ws_pack_weight: needs Cout %% 32 == 0 and Cin 32, 64 or 128 (got %d, %d)",
                 Cout, Cin);
     DVC_REQUIRE((reinterpret_cast<uintptr_t>(u_packed) & 15) == 0, "dvc_conv2d_ws_pack_weight: destination must be 16-byte aligned");
     const long n = (long)Cout * Cin * 9;
@@ -247,7 +249,7 @@ static int ws_num_cus() {
 extern "C" int dvc_conv2d_ws(const DvcConvDesc* d, const float* x, const float* u_packed, const float* bias, const float* act_slope_ptr,
                              float* y, dvcStream stream) {
     DVC_REQUIRE(d && x && u_packed && y, "dvc_conv2d_ws: null argument");
-    DVC_REQUIRE(dvc_conv2d_ws_eligible(d), "dvc_conv2d_ws: needs a 3x3 stride-1 pad-1 zero-padded layer with 32 or 64 input channels, "
+    DVC_REQUIRE(dvc_conv2d_ws_eligible(d), "dvc_conv2d_ws: needs a 3x3 stride-1 pad-1 zero-padded layer with 32, 64 or 128 input channels, "
                                            "Cout %% 64 == 0 and no fused input transform");
     DVC_REQUIRE((reinterpret_cast<uintptr_t>(u_packed) & 15) == 0, "dvc_conv2d_ws: weights must be 16-byte aligned");
     ConvWsArgs a;
@@ -259,8 +261,9 @@ extern "C" int dvc_conv2d_ws(const DvcConvDesc* d, const float* x, const float* 
     a.strips = cdiv(d->W, 32);
     const int ps = d->Cin == 32 ? 2 : 1;
     const int coblk = d->Cout / 64;
-    // rows per workgroup: as many workgroups as the chip holds at once (two per CU), per image — never a function of the batch
-    const int slots = 2 * ws_num_cus();
+    // rows per workgroup: as many workgroups as the chip holds at once (two four-wave ones per CU, or one of eight waves), per
+    // image — never a function of the batch
+    const int slots = (d->Cin == 128 ? 1 : 2) * ws_num_cus();
     int nchunk = slots / (a.strips * coblk);
     if (nchunk < 1) nchunk = 1;
     int rpw = cdiv(d->H, nchunk);
@@ -270,7 +273,8 @@ extern "C" int dvc_conv2d_ws(const DvcConvDesc* d, const float* x, const float* 
     dim3 grid((unsigned)(a.strips * a.chunks), (unsigned)coblk, (unsigned)d->N);
     hipStream_t st = (hipStream_t)stream;
     if (d->Cin == 32) hipLaunchKernelGGL((conv_ws_kernel<1, 2, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_ws_kernel<2, 2, 1>), grid, dim3(256), 0, st, a);
+    else if (d->Cin == 64) hipLaunchKernelGGL((conv_ws_kernel<2, 2, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_ws_kernel<4, 2, 1>), grid, dim3(512), 0, st, a);
     DVC_CHECK_LAUNCH("dvc_conv2d_ws");
     return 0;
 }

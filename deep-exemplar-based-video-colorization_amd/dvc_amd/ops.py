@@ -208,8 +208,8 @@ def set_ws_conv(flag=True):
 
 def ws_eligible(Cin, Cout, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1, act=ACT_NONE):
     """Geometry the weights-in-registers kernel takes (dvc_conv2d_ws_eligible): 3x3 stride 1 pad 1, zero padding, plain input,
-    32 or 64 input channels, Cout % 64 == 0."""
-    return (Cin in (32, 64) and Cout % 64 == 0 and dil == 1 and pad_mode == PAD_ZERO and in_up == 1 and in_sub == 1
+    32, 64 or 128 input channels, Cout % 64 == 0."""
+    return (Cin in (32, 64, 128) and Cout % 64 == 0 and dil == 1 and pad_mode == PAD_ZERO and in_up == 1 and in_sub == 1
             and act in (ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LEAKY))
 
 

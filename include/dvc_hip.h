@@ -170,7 +170,7 @@ int dvc_conv2d_winograd_dual(const DvcConvDesc* dA, const DvcConvDesc* dB, const
  * added to a running total), another decomposition — a wave keeps its 32 x 32 x 9 filter block in 144 VGPRs for the whole
  * launch and walks down a 32-pixel column strip whose input rows stream through an LDS ring.
  * Eligible (dvc_conv2d_ws_eligible != 0): ksize 3, stride 1, dil 1, pad 1, zero padding, no up / sub-sampling, no fused input
- * transform, Cin 32 or 64, Cout % 64 == 0, act NONE / RELU / PRELU / LEAKY; no residual.  `u_packed`: Cout * Cin * 9 floats
+ * transform, Cin 32, 64 or 128, Cout % 64 == 0, act NONE / RELU / PRELU / LEAKY; no residual.  `u_packed`: Cout * Cin * 9 floats
  * written by dvc_conv2d_ws_pack_weight from the module's [Cout][Cin][3][3] weight (fragment order, 16-byte aligned).
  * x_batch_stride / y_batch_stride of the descriptor are honoured; cfg / split_k / flags are ignored (one plan per geometry,
  * per image: a batch of N is bit-identical to N calls). */

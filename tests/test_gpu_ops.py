@@ -382,7 +382,8 @@ def test_conv2d_winograd_dual(ops, N, CA, CB, Cout, H, W, upA, upB, act):
 @pytest.mark.parametrize("N,Cin,Cout,H,W,act,bias", [
     (1, 64, 64, 216, 384, 1, True), (1, 32, 64, 216, 384, 1, True), (2, 64, 128, 108, 192, 1, True),
     (1, 64, 64, 13, 37, 0, True), (1, 32, 64, 7, 5, 3, False), (1, 32, 128, 9, 70, 2, True), (3, 64, 64, 1, 1, 1, True),
-    (1, 64, 192, 33, 33, 0, False), (1, 32, 64, 2, 32, 1, True)])
+    (1, 64, 192, 33, 33, 0, False), (1, 32, 64, 2, 32, 1, True),
+    (1, 128, 128, 108, 192, 1, True), (2, 128, 256, 54, 96, 1, True), (1, 128, 64, 9, 33, 2, False)])
 def test_conv2d_ws_weights_in_registers_engine(ops, N, Cin, Cout, H, W, act, bias):
     """dvc_conv2d_ws (r06, csrc/conv_ws.hip): the large-map / few-channel 3x3 layers with the filters resident in registers.
     Against a float64 convolution (the direct engine's tolerance, 2e-5 relative; measured ~1e-6) and against the general direct
