@@ -86,16 +86,26 @@ def evaluate(name, setup):
         "(max/q999/mean): " + "  ".join("flip" if p is None else f"{p[0]:.2f}/{p[1]:.2f}/{p[2]:.2f}" for p in per))
 
 
-def cfg(ws=True, group=True, tune=False, extra_direct=(), algo="auto"):
+def cfg(ws=True, group=True, tune=False, extra_direct=(), algo="auto", drop=()):
     def f():
         ops.set_conv_algo(algo)
         ops.set_ws_conv(ws)
         ops.set_group_heads(group)
         ops.set_autotune(tune)
-        ops.set_direct_layers(None if not extra_direct else frozenset(arch.DIRECT_LAYERS) | frozenset(extra_direct))
+        ops.set_direct_layers(None if not (extra_direct or drop) else (frozenset(arch.DIRECT_LAYERS) | frozenset(extra_direct)) - frozenset(drop))
     return f
 
 
+if os.environ.get("PROBE_MAPS") == "1":     # candidate engine maps (which of the map's layers could go back to Winograd)
+    evaluate("default", cfg())
+    evaluate("default + autotune", cfg(tune=True))
+    evaluate("map - conv3_3", cfg(drop=("cvn.conv3_3",)))
+    evaluate("map - conv3_2", cfg(drop=("cvn.conv3_2",)))
+    evaluate("map - conv3_2, conv3_3", cfg(drop=("cvn.conv3_2", "cvn.conv3_3")))
+    evaluate("map - conv3_2, conv3_3 + autotune", cfg(drop=("cvn.conv3_2", "cvn.conv3_3"), tune=True))
+    evaluate("map - conv3_1, conv3_2, conv3_3", cfg(drop=("cvn.conv3_1", "cvn.conv3_2", "cvn.conv3_3")))
+    open("gpurun_out/parity_pool_probe_maps.txt", "w").write("\n".join(lines) + "\n")
+    sys.exit(0)
 evaluate("default (ws, grouped)", cfg())
 evaluate("default + autotune (bench)", cfg(tune=True))
 evaluate("ws off", cfg(ws=False))
