@@ -106,6 +106,7 @@ __global__ __launch_bounds__(64 * KH * CT * PS) __attribute__((amdgpu_waves_per_
     // rows y_begin - 1 .. y_begin + PS of the first step (issued before the filter loads: the two round trips overlap)
 #pragma unroll
     for (int k = -1; k <= PS; ++k) issue_row(y_begin + k);
+    asm volatile("" ::: "memory");      // (the filter loads below must stay BEHIND the row DMAs: the vmcnt(36) further down counts on it)
     // ---- filters: 144 A fragments, 36 x 16 bytes per lane
     float A[144];
     {
