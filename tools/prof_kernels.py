@@ -55,5 +55,12 @@ for (ci, co, H, W, dil, up) in [(256, 256, 54, 96, 1, 1), (512, 512, 27, 48, 1, 
     b = torch.randn(co, device=dev)
     for _ in range(3):
         ops.conv2d_winograd(x, u, b, dil=dil, in_up=up, act=1)
+# r06: the weights-in-registers direct kernel (csrc/conv_ws.hip) on the engine-map layers it takes
+for (ci, co, H, W) in [(64, 64, 216, 384), (32, 64, 216, 384), (64, 128, 108, 192), (128, 128, 108, 192), (128, 256, 54, 96), (128, 128, 216, 384)]:
+    x = torch.randn(1, ci, H, W, device=dev)
+    u = ops.pack_ws_weight(torch.randn(co, ci, 3, 3, device=dev) * 0.05)
+    b = torch.randn(co, device=dev)
+    for _ in range(3):
+        ops.conv2d_ws(x, u, b, co, act=1)
 torch.cuda.synchronize()
 print("done")
