@@ -199,16 +199,16 @@ def cpu_baseline(sd):
             "by_threads": {str(k): v for k, v in sorted(legs.items())}}
 
 
-def parity_block(cc, sd, device, n_pool=4):
+def parity_block(cc, sd, device, n_pool=6):
     """Untimed: how far the TIMED engine is from the fp64 truth at the timed configuration, next to the reference-equivalent
     CPU fp32 run against the same truth (SURVEY.md 7 hard part 1 / 8c: "must be <= the CPU figure").  216x384 frames as first
     frames of a clip (exemplar seed 2, frame seeds 1000.., the plain seed-0 weights `value` is measured with), T = 1e-10; the
     oracle runs on the host CPU in fp32 and fp64 (checker only).
-    Top level: frame 1000 alone, as r05 reported it.  r06 adds what calibrates those numbers: `cpu32_other_thread_count` — the
-    SAME reference arithmetic at another ATen thread count against the same truth (with the chaotic random weights the tail of
-    one frame's error field is a lottery over rounding noise: the reference's own q99.9 / max move by 1.5x / 2x between thread
-    counts on this frame) — and `pooled`: the same ratios over `n_pool` frames (frames on which an arg-max differs from the
-    truth's are left out on both sides).  tests/test_gpu_nets.py asserts the single-frame and the pooled comparison."""
+    r06: the top-level ratios are POOLED over `n_pool` frames (frames on which an arg-max differs from the truth's are left out on
+    both sides); `frame_1000` is what r05 reported (that frame alone) and `cpu32_other_thread_count` calibrates it — the SAME
+    reference arithmetic at another ATen thread count against the same truth: with the chaotic random weights the tail of one
+    frame's error field is a lottery over rounding noise, the reference's own q99.9 / max move by 1.5x / 2x between thread
+    counts on that frame.  tests/test_gpu_nets.py asserts the pooled and the single-frame comparison."""
     import numpy as np
     from dvc_amd import ops, synth
     from oracle import dvc_oracle as O
@@ -265,19 +265,23 @@ def parity_block(cc, sd, device, n_pool=4):
                 speed = {"gpu_vs_fp64": sig(gs), "gpu_over_cpu32": rat(gs, c)}
             finally:
                 ops.set_conv_algo("auto")
-        return {"gpu_vs_fp64": sig(g), "cpu32_vs_fp64": sig(c), "gpu_over_cpu32": rat(g, c), "conv_algo": ops.conv_algo(),
-                "direct_layers": sorted(ops.direct_layers()) if ops.conv_algo() == "auto" else None,
-                "cpu32_other_thread_count": {"threads": k_other, "vs_fp64": sig(co), "over_cpu32": rat(co, c), "gpu_over_it": rat(g, co),
+        top = pooled if pooled is not None else {"gpu_vs_fp64": sig(g), "cpu32_vs_fp64": sig(c), "gpu_over_cpu32": rat(g, c), "frames": 1}
+        return {"gpu_vs_fp64": top["gpu_vs_fp64"], "cpu32_vs_fp64": top["cpu32_vs_fp64"], "gpu_over_cpu32": top["gpu_over_cpu32"],
+                "frames_pooled": top["frames"], "per_frame": per_frame,
+                "frame_1000": {"gpu_vs_fp64": sig(g), "cpu32_vs_fp64": sig(c), "gpu_over_cpu32": rat(g, c)},
+                "cpu32_other_thread_count": {"threads": k_other, "frame_1000_vs_fp64": sig(co), "over_cpu32": rat(co, c), "gpu_over_it": rat(g, co),
                                              "note": f"the reference arithmetic itself (oracle, torch CPU fp32) at {k_other} instead of "
-                                                     f"{k_main} threads against the same fp64 truth: how much of a single frame's tail "
-                                                     "ratio is rounding-noise lottery (profiles/r06_parity_hotspot.txt, "
+                                                     f"{k_main} threads against the same fp64 truth on frame 1000: how much of a single "
+                                                     "frame's tail ratio is rounding-noise lottery (profiles/r06_parity_hotspot.txt, "
                                                      "r06_parity_pool_probe.txt)"},
-                "pooled": pooled,
+                "conv_algo": ops.conv_algo(), "direct_layers": sorted(ops.direct_layers()) if ops.conv_algo() == "auto" else None,
                 "engine_speed_for_comparison": speed,
                 "sample": "ab of 216x384 frames as first frames of a clip (exemplar seed 2, frame seeds 1000.., plain seed-0 weights, "
                           "T = 1e-10): |GPU fp32 - oracle fp64| and |oracle fp32 (= the reference's CPU run) - oracle fp64| over the "
-                          f"2 x 216 x 384 values; top level = frame 1000, `pooled` = {len(eg_all)} frames; untimed, oracle on the host "
-                          f"CPU ({t_cpu:.0f} s)"}
+                          f"2 x 216 x 384 values per frame.  Top level = POOLED over the {top['frames']} frames without an arg-max "
+                          "flip (r05 reported frame 1000 alone: `frame_1000`; one frame's q99.9 / max are a lottery over rounding "
+                          "noise — the reference's own run moves by `cpu32_other_thread_count.over_cpu32` between thread counts); "
+                          f"engine_speed_for_comparison: frame 1000; untimed, oracle on the host CPU ({t_cpu:.0f} s)"}
     finally:
         torch.set_num_threads(keep)
 
@@ -415,7 +419,13 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="issue every kernel launch from Python instead of replaying the captured per-frame launch sequences "
                          "(hipGraph, dvc_amd/graph.py); results are bit-identical either way")
-    ap.add_argument("--no-autotune", action="store_true", help="use the static tile cost model instead of first-use timing")
+    ap.add_argument("--autotune", action="store_true",
+                    help="time the general direct engine's tile / split candidates on first use (the analogue of cudnn.benchmark = True, "
+                         "test.py:140) instead of the library's static plan.  Off by default since r06: the tuner's picks differ "
+                         "from run to run, every pick is another summation order, and with the chaotic random weights that "
+                         "re-draws the tail of a frame's error field (profiles/r06_parity_pool_probe.txt) — with the static plan "
+                         "the timed arithmetic is EXACTLY the arithmetic the parity tests assert; it is worth +0.4 % frames/s")
+    ap.add_argument("--no-autotune", action="store_true", help="(default since r06; kept for old command lines)")
     ap.add_argument("--min-timed-s", type=float, default=0.5,
                     help="the K-step clip is repeated until at least this much GPU work has been timed (>= 3 repeats); the line "
                          "reports the median repeat with p10 / p90")
@@ -489,7 +499,7 @@ def main():
     from dvc_amd.frame import ClipColorizer
     from dvc_amd.parallel import broadcast_exemplar
 
-    ops.set_autotune(not args.no_autotune)   # like the reference's cudnn.benchmark = True (test.py:140)
+    ops.set_autotune(bool(args.autotune) and not args.no_autotune)
     nets, sd = build_nets(device)
     nets[1].corr_precision = args.corr
     use_graph = not args.no_graph and not args.no_exemplar_cache and args.front_batch == 1
@@ -829,8 +839,8 @@ def main():
         cpu = cpu_baseline(sd)
         if (H, W) == (216, 384) and not args.no_parity:
             parity = parity_block(cc, sd, device)
-            log(f"[bench] parity vs fp64: GPU {parity['gpu_vs_fp64']}  CPU fp32 {parity['cpu32_vs_fp64']}  pooled "
-                f"{parity['pooled'] and parity['pooled']['gpu_over_cpu32']}")
+            log(f"[bench] parity vs fp64, pooled over {parity['frames_pooled']} frames: GPU / CPU fp32 {parity['gpu_over_cpu32']}; frame 1000 "
+                f"{parity['frame_1000']['gpu_over_cpu32']}; the reference at another thread count {parity['cpu32_other_thread_count']['over_cpu32']}")
 
     other = None
     if (rank == 0 and n_gpus == 1 and (H, W) == (216, 384) and args.corr == "fp32" and args.lookahead > 0 and args.other_steps > 0
@@ -874,8 +884,8 @@ def main():
                                                    "rule only, no error-aware map)",
                                           "winograd": "Winograd F(2x2,3x3) on every eligible 3x3 layer",
                                           "direct": "direct implicit GEMM everywhere"}[ops.conv_algo()],
-                       "conv_tile_choice": "static cost model" if args.no_autotune else
-                       "autotuned on first use during warm-up (cf. cudnn.benchmark=True, test.py:140)",
+                       "conv_tile_choice": "autotuned on first use during warm-up (cf. cudnn.benchmark=True, test.py:140)"
+                       if ops.autotune_enabled() else "the library's static plan (deterministic: the arithmetic the parity tests assert)",
                        "frames_per_gpu": K, "parallelism": f"frame-chunks x{n_gpus}",
                        "repeats": repeats, "ms_per_step_p10": round(pick(0.1) / K * 1e3, 4),
                        "ms_per_step_p90": round(pick(0.9) / K * 1e3, 4),

@@ -58,7 +58,7 @@ def table(prefix, title, note):
              "|---|---|---|---|---|---|---|---|---|---|"]
     n0 = len(lines)
     for k, v in agg.items():
-        if "conv_mfma" not in k and "corr_fwd" not in k and "conv_sk_kernel" not in k and "conv_wino" not in k:
+        if "conv_mfma" not in k and "corr_fwd" not in k and "conv_sk_kernel" not in k and "conv_wino" not in k and "conv_ws_kernel" not in k:
             continue
         c = {n: sum(x) / len(x) for n, x in v.items()}
         if "GRBM_GUI_ACTIVE" not in c:
@@ -67,7 +67,7 @@ def table(prefix, title, note):
         cyc = c["GRBM_GUI_ACTIVE"] / 8
         w = c["SQ_WAVES"]
         lines.append("| `%s` | %.0f | %.2f | %d | %.1f%% | %.0f / %.0f / %.0f / %.0f / %.0f | %.0f | %.0f | %.1f | %.1f |" % (
-            k.replace("void ", "").replace("(ConvKArgs)", "").replace("(CorrArgs)", "").replace("(ConvSkArgs)", "").replace("(ConvWinoArgs)", ""), us, cyc / us / 1e3, w,
+            k.replace("void ", "").replace("(ConvKArgs)", "").replace("(CorrArgs)", "").replace("(ConvSkArgs)", "").replace("(ConvWinoArgs)", "").replace("(ConvWsArgs)", ""), us, cyc / us / 1e3, w,
             100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), c["SQ_WAVE_CYCLES"] * 4 / w / 1e3,
             c["SQ_VALU_MFMA_BUSY_CYCLES"] / w / 1e3, c["SQ_ACTIVE_INST_ANY"] * 4 / w / 1e3,
             c["SQ_WAIT_INST_ANY"] * 4 / w / 1e3, c.get("SQ_WAIT_ANY", 0) * 4 / w / 1e3, c.get("SQ_INSTS_VALU", 0) / w,
