@@ -282,6 +282,110 @@ __global__ __launch_bounds__(256) void fgs_solve_scan_kernel(float* __restrict__
     }
 }
 
+// ---- r06: the COLUMN solves without the two transpositions around them (r05: transpose -> row-form scan -> transpose back, six
+// transpositions per frame = 21 % of the tail's kernel time).  Same scan, same arithmetic in the same order (bit-identical to the
+// transposed form); what changes is how a line reaches its wave.  A workgroup = 16 waves = 16 ADJACENT columns: the 16 x L tile of
+// the row-major image is read cooperatively (a row of the tile = 64 contiguous bytes) into LDS, column-major in the blocked
+// order the scan wants (lane j's E consecutive elements contiguous, odd pitch), each wave scans its column — the
+// coefficients of the column system are line-major already (fgs_coeff_window_kernel writes [guide][W][H]), so a lane reads its E
+// consecutive values of ap / inv / c' straight from memory — and the tile goes back the way it came.
+#define FGS_COLS 16
+template <int E>
+__global__ __launch_bounds__(64 * FGS_COLS) void fgs_solve_scan_cols_kernel(float* __restrict__ f, const float* __restrict__ ap,
+                                                                            const float* __restrict__ inv, const float* __restrict__ cp,
+                                                                            int L, int ncols, int planes_per_guide) {
+    constexpr int EP = E | 1;
+    constexpr int PITCH = 64 * EP + 1;                      // (+1: the 16 columns of one tile row land in 16 different banks)
+    __shared__ float sG[FGS_COLS * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = blockIdx.x * FGS_COLS;
+    const int plane = blockIdx.y;
+    float* fpl = f + (long)plane * L * ncols;               // [L][ncols]: element l of column x at l * ncols + x
+    // tile in: thread = (row r of a 64-row pass, column cx)
+    const int cx = tid & (FGS_COLS - 1), r0 = tid / FGS_COLS;
+    const bool colok = x0 + cx < ncols;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int l = k * 64 + r0;
+        if (l < L && colok) sG[cx * PITCH + (l / E) * EP + (l % E)] = fpl[(long)l * ncols + x0 + cx];
+    }
+    __syncthreads();
+    const int col = x0 + wv;
+    const bool active = col < ncols;
+    if (active) {
+        const long goff = ((long)(plane / planes_per_guide) * ncols + col) * L + lane * E;
+        float a[E], g[E], c[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const bool ok = lane * E + k < L;
+            a[k] = ok ? ap[goff + k] : 0.f;
+            g[k] = ok ? sG[wv * PITCH + lane * EP + k] * inv[goff + k] : 0.f;
+            c[k] = ok ? -cp[goff + k] : 0.f;
+        }
+        // (from here on: fgs_solve_scan_kernel's arithmetic, statement for statement)
+        float P = 1.f, S = 0.f;
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            S = fmaf(a[k], S, g[k]);
+            P *= a[k];
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float Pp = __shfl_up(P, off), Sp = __shfl_up(S, off);
+            if (lane >= off) {
+                S = fmaf(P, Sp, S);
+                P *= Pp;
+            }
+        }
+        float d = __shfl_up(S, 1);
+        if (lane == 0) d = 0.f;
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            d = fmaf(a[k], d, g[k]);
+            g[k] = d;
+        }
+        P = 1.f, S = 0.f;
+#pragma unroll
+        for (int k = E - 1; k >= 0; --k) {
+            S = fmaf(c[k], S, g[k]);
+            P *= c[k];
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float Pp = __shfl_down(P, off), Sp = __shfl_down(S, off);
+            if (lane + off < 64) {
+                S = fmaf(P, Sp, S);
+                P *= Pp;
+            }
+        }
+        float u = __shfl_down(S, 1);
+        if (lane == 63) u = 0.f;
+#pragma unroll
+        for (int k = E - 1; k >= 0; --k) {
+            u = fmaf(c[k], u, g[k]);
+            sG[wv * PITCH + lane * EP + k] = u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int l = k * 64 + r0;
+        if (l < L && colok) fpl[(long)l * ncols + x0 + cx] = sG[cx * PITCH + (l / E) * EP + (l % E)];
+    }
+}
+
+static void fgs_solve_scan_cols(hipStream_t s, float* f, const float* ap, const float* inv, const float* cp, int L, int ncols, int planes,
+                                int planes_per_guide) {
+    const dim3 grid(cdiv(ncols, FGS_COLS), planes);
+#define FGS_SCANC(E_) case E_: hipLaunchKernelGGL((fgs_solve_scan_cols_kernel<E_>), grid, dim3(64 * FGS_COLS), 0, s, f, ap, inv, cp, L, ncols, planes_per_guide); break;
+    switch (cdiv(L, 64)) {
+        FGS_SCANC(1) FGS_SCANC(2) FGS_SCANC(3) FGS_SCANC(4) FGS_SCANC(5) FGS_SCANC(6) FGS_SCANC(7) FGS_SCANC(8)
+        FGS_SCANC(9) FGS_SCANC(10) FGS_SCANC(11) FGS_SCANC(12) FGS_SCANC(13) FGS_SCANC(14) FGS_SCANC(15) FGS_SCANC(16)
+        default: break;
+    }
+#undef FGS_SCANC
+}
+
 // ---- r05: the elimination coefficients without the L-long chain.  c'_l = c_l / (b_l - a_l c'_{l-1}) FORGETS its start: the
 // map is a contraction whose rate is largest for a flat guide (all weights 1), rho(lambda) = x*^2 with x* the fixed point
 // -((1 + 2 lambda) - sqrt(1 + 4 lambda)) / (2 lambda) — 0.865 for the first iteration's lambda_1 = 190 (lambda = 500), 0.75 and
@@ -577,9 +681,8 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
         if (scan) {
             // rows in place on the image; columns on the transposed image
             fgs_solve_scan(s, dst, row_lm + 2 * IT + it * GHW, row_lm + IT + it * GHW, row_lm + it * GHW, W, H, planes, planes_per_guide);
-            hipLaunchKernelGGL(transpose_kernel, tgrid_fwd, dim3(256), 0, s, dst, H, W, tr);
-            fgs_solve_scan(s, tr, col_lm + 2 * IT + it * GHW, col_lm + IT + it * GHW, col_lm + it * GHW, H, W, planes, planes_per_guide);
-            hipLaunchKernelGGL(transpose_kernel, tgrid_bwd, dim3(256), 0, s, tr, W, H, dst);
+            // columns in place too (r06): 16-column tiles through LDS instead of a transposed copy of the image
+            fgs_solve_scan_cols(s, dst, col_lm + 2 * IT + it * GHW, col_lm + IT + it * GHW, col_lm + it * GHW, H, W, planes, planes_per_guide);
         } else {
             // rows: every image row is a line of length W; in the transposed image [W][H] it runs along axis 0
             hipLaunchKernelGGL(transpose_kernel, tgrid_fwd, dim3(256), 0, s, dst, H, W, tr);
