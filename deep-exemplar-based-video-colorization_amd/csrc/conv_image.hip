@@ -66,8 +66,16 @@ __global__ __launch_bounds__(256) void conv_image_kernel(ConvKArgs a, int tiles_
         const int iy = e / (TW + 2), ix = e - iy * (TW + 2);
         const int o = e < PE ? stored_offset(a, ty0 - 1 + iy, tx0 - 1 + ix) : -1;
         float v[CIN];
+        if (a.gray) {
+            // DVC_CONV_GRAY_INPUT: every virtual channel is gray2rgb_batch's value of the ONE stored plane, with that kernel's
+            // own expression (csrc/color.hip: bit-identical to running it first)
+            const float g = (xn[max(o, 0)] * 1.0f + 50.0f) / 100.0f;
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) v[c] = xn[c * HW + max(o, 0)];
+            for (int c = 0; c < CIN; ++c) v[c] = g;
+        } else {
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) v[c] = xn[c * HW + max(o, 0)];
+        }
         if (e < PE) {
 #pragma unroll
             for (int c = 0; c < CIN; ++c) patch[c * PLANE + iy * PITCH + ix] = o >= 0 ? v[c] * sc[c] + sh[c] : 0.f;
@@ -129,6 +137,7 @@ __global__ __launch_bounds__(256) void conv_image_kernel(ConvKArgs a, int tiles_
 // (3 -> 64) and (7 -> 32): the two image-input layers of the path.  Returns false when the layer is not one of them.
 bool conv_image_launch(const ConvKArgs& a, hipStream_t st) {
     if (a.ks != 3 || a.stride != 1 || a.dil != 1 || a.pad != 1 || a.in_up != 1 || a.in_sub != 1 || a.in_prelu || a.res) return false;
+    if (a.gray && !(a.Cin == 3 && a.Cout == 64)) return false;
     const int tiles_x = (a.OW + 31) / 32, tiles_y = (a.OH + 7) / 8;
     if ((long)tiles_x * tiles_y >= (1L << 31) || a.N > 65535 || (long)a.Cout * a.OH * a.OW >= (1L << 31)) return false;
     const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)a.N);

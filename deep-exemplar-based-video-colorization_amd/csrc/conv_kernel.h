@@ -62,6 +62,7 @@ struct ConvKArgs {
     int chunks_per_split;
     float* part;           // [S][N][Cout][OH][OW]
     long long* dbg_buf;    // timing experiments only: per-workgroup {start, end, HW_ID, XCC_ID} (dvc_debug_conv_trace)
+    int gray;              // DVC_CONV_GRAY_INPUT (conv_image_kernel only): the stored input is ONE plane of centred luminance
     int dbg;               // timing experiments only (dvc_debug_conv_variant): 1 = no DMA after the first chunk,
                            // 2 = no patch DMA, 3 = no weight DMA after the first chunk (results are wrong)
 };

@@ -194,7 +194,8 @@ static int conv2d_images(const DvcConvDesc* d, const float* x, const float* w_pa
     a.ks = d->ksize; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.pad_mode = d->pad_mode;
     a.in_up = d->in_up; a.in_sub = d->in_sub; a.act = d->act; a.in_prelu = d->in_prelu;
     a.act_slope = d->act_slope;
-    a.x_bs = d->x_batch_stride ? d->x_batch_stride : (long)d->Cin * d->H * d->W;
+    a.gray = (d->flags & DVC_CONV_GRAY_INPUT) ? 1 : 0;
+    a.x_bs = d->x_batch_stride ? d->x_batch_stride : (long)(a.gray ? 1 : d->Cin) * d->H * d->W;
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long)d->Cout * OH * OW;
     a.res_bs = d->res_batch_stride ? d->res_batch_stride : (long)d->Cout * OH * OW;
     a.cin_pad = (d->Cin + 3) & ~3;
@@ -211,6 +212,7 @@ static int conv2d_images(const DvcConvDesc* d, const float* x, const float* w_pa
         DVC_CHECK_LAUNCH("dvc_conv2d(image-input layer)");
         return 0;
     }
+    DVC_REQUIRE(!a.gray, "dvc_conv2d: DVC_CONV_GRAY_INPUT is for the 3 -> 64 image-input layer under the automatic plan only");
     const int tw = pick_tw(OW);
     const int rpt = 32 / tw;
     // stride 1: geometry is baked into the kernel (one variant per ksize/dilation); stride 2 (and a
@@ -390,7 +392,7 @@ extern "C" int dvc_conv2d(const DvcConvDesc* d, const float* x, const float* w_p
     DvcConvDesc g = *d;
     int32_t OH = 0, OW = 0;
     dvc_conv2d_out_hw(d, &OH, &OW);
-    const long x_bs = d->x_batch_stride ? d->x_batch_stride : (long)d->Cin * d->H * d->W;
+    const long x_bs = d->x_batch_stride ? d->x_batch_stride : (long)((d->flags & DVC_CONV_GRAY_INPUT) ? 1 : d->Cin) * d->H * d->W;
     const long y_bs = d->y_batch_stride ? d->y_batch_stride : (long)d->Cout * OH * OW;
     const long r_bs = d->res_batch_stride ? d->res_batch_stride : (long)d->Cout * OH * OW;
     g.x_batch_stride = x_bs; g.y_batch_stride = y_bs; g.res_batch_stride = r_bs;
@@ -608,7 +610,7 @@ static int wino_setup(const DvcConvDesc* d, const DvcConvDesc* d2, const float* 
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : (long)d->Cout * OH * OW;
     a.res_bs = d->res_batch_stride ? d->res_batch_stride : (long)d->Cout * OH * OW;
     a.cin_pad = d->Cin; a.IH_T = a.IW_T = a.IW_P = 0;
-    a.dbg = g_conv_dbg; a.dbg_buf = nullptr; a.w_bs = 0;
+    a.dbg = g_conv_dbg; a.dbg_buf = nullptr; a.w_bs = 0; a.gray = 0;
     s.ss = d->dil;
     const int TY = cdiv(cdiv(OH, s.ss), 2), TX = cdiv(cdiv(OW, s.ss), 2);   // 2x2 tiles of one parity class
     int best_m = -1, best_tr = 1, best_S = 1;

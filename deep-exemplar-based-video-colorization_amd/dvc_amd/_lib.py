@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DVC_DEBUG_LIB=1 (tools/ only) loads the -DDVC_DEBUG build, the only one that carries the dvc_debug_* hooks
 DEBUG_BUILD = os.environ.get("DVC_DEBUG_LIB", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "libdvc_hip_debug.so" if DEBUG_BUILD else "libdvc_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32

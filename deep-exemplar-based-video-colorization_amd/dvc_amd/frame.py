@@ -15,8 +15,12 @@ def warp_color(IA_l, IB_lab, features_B, vggnet, nonlocal_net, colornet, feature
     """models/FrameColor.py:5-38.  `colornet` and `feature_noise` are unused there as well.
     defer_merge (not upstream): the correlation's merge is left to ops.pack_color_input — `nonlocal_BA_lab` is then an
     ops.CorrPartials and `similarity_map` None (the fp32 correlation only; the bf16 candidate filter returns tensors)."""
-    IA_rgb_from_gray = gray2rgb_batch(IA_l)
-    A_relu1_1, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1 = vggnet(IA_rgb_from_gray, VGG_OUT, preprocess=True)
+    if ops.gray_fusion() and hasattr(vggnet, "forward_gray") and IA_l.is_cuda:
+        # gray2rgb_batch folded into conv1_1's load (bit-identical, one launch less; DVC_GRAY_FUSION=0 restores the two calls)
+        A_relu1_1, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1 = vggnet.forward_gray(IA_l, VGG_OUT)
+    else:
+        IA_rgb_from_gray = gray2rgb_batch(IA_l)
+        A_relu1_1, A_relu2_1, A_relu3_1, A_relu4_1, A_relu5_1 = vggnet(IA_rgb_from_gray, VGG_OUT, preprocess=True)
     if exemplar_cache is None:
         B_relu1_1, B_relu2_1, B_relu3_1, B_relu4_1, B_relu5_1 = features_B
     # NOTE: output the feature before normalization (FrameColor.py:13-14)

@@ -26,7 +26,7 @@ from . import nets, ops
 def _epoch():
     """Everything that decides WHICH launches a sequence consists of."""
     return (nets.pack_epoch(), ops.conv_algo(), ops.fuse_reduce(), ops.pool_fusion(), ops.dual_conv_enabled(), ops.autotune_enabled(),
-            ops.fold_merge(), ops.direct_layers(), ops.batch_plan_enabled(), ops.group_heads(), ops.ws_conv_enabled())
+            ops.fold_merge(), ops.direct_layers(), ops.batch_plan_enabled(), ops.group_heads(), ops.ws_conv_enabled(), ops.gray_fusion())
 
 
 class CapturedSequence:

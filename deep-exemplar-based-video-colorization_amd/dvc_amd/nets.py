@@ -172,9 +172,15 @@ class VGG19_pytorch(nn.Module):
         self._packed("conv1_1", swap_bgr=True)
         self._pre_affine()
 
-    def forward(self, x, out_keys, preprocess=True):
+    def forward_gray(self, IA_l, out_keys):
+        """forward(gray2rgb_batch(IA_l), out_keys, preprocess=True) — the call FrameColor.py:8-10 makes — with the grey-to-RGB
+        replication folded into conv1_1's load (DVC_CONV_GRAY_INPUT): IA_l is the centred luminance [N,1,H,W] (a channel slice
+        of the Lab frame is fine).  Bit-identical to the two-step form, one launch and a 1 MB tensor less per frame."""
+        return self.forward(IA_l, out_keys, preprocess=True, _gray=True)
+
+    def forward(self, x, out_keys, preprocess=True, _gray=False):
         _check_input(x, "VGG19_pytorch")
-        x = x.detach().contiguous().float()
+        x = x.detach().float() if _gray else x.detach().contiguous().float()
         N = x.shape[0]
         for k in out_keys:
             if k not in arch.VGG_KEYS:
@@ -212,7 +218,7 @@ class VGG19_pytorch(nn.Module):
                     # vgg_preprocess folded into the load (BGR weight flip + per-channel affine)
                     sc, sh = self._pre_affine(N)
                     cur = ops.conv2d(cur, self._packed(name, swap_bgr=True), bias, act=ops.ACT_RELU,
-                                     in_scale=sc, in_shift=sh)
+                                     in_scale=sc, in_shift=sh, gray_input=_gray)
                 else:
                     cur = ops.conv3x3(cur, conv.weight, _packs(self._cache, name, conv.weight), bias, act=ops.ACT_RELU,
                                       layer="vgg." + name)
@@ -329,23 +335,23 @@ class WarpNet(nn.Module):
 
         # stage 1: first convolutions
         t1 = ops.conv3x3_group([conv_item(f"{hd['name']}.{hd['ia']}", hd["ca"], hd["x"], defer_reduce=hd["sb"] == 1) for hd in heads])
-        # stage 2: InstanceNorm + PReLU, materialised (one launch, in place where the convolution wrote a tensor) so that the
-        # next convolution has no fused input transform and stages through LDS-DMA; the stride-2 convolution (register
-        # staging anyway) applies them on load instead
-        plain = [k for k, hd in enumerate(heads) if hd["sb"] == 1]
+        # stage 2: InstanceNorm + PReLU, materialised (one launch for the four heads, in place where the convolution wrote a
+        # tensor) so that the next convolution has no fused input transform.  r06: the stride-2 head too — up to r05 its
+        # statistics were a launch of their own and the stride-2 convolution applied them on load; as an item of the grouped
+        # launch the norm costs nothing extra, and the convolution (run-time-geometry kernel, register staging either way)
+        # reads the normalised tensor
         normed = ops.instnorm_apply_group([dict(x=t1[k], out=None if isinstance(t1[k], ops.ConvPartials) else t1[k],
-                                                slope_t=heads[k]["seq"][heads[k]["pa"]].weight.detach()) for k in plain])
+                                                slope_t=hd["seq"][hd["pa"]].weight.detach()) for k, hd in enumerate(heads)])
+        plain = [k for k, hd in enumerate(heads) if hd["sb"] == 1]
         t2 = [None] * len(heads)
         for k, hd in enumerate(heads):      # (before the grouped launch: a split-K direct convolution uses the same workspace)
             if hd["sb"] != 1:
-                sc, sh = ops.instnorm_stats(t1[k])
-                t2[k] = ops.conv2d(t1[k], self._pk(f"{hd['name']}.{hd['ib']}", hd["cb"]), hd["cb"].bias.detach(), stride=hd["sb"],
-                                   pad_mode=ops.PAD_REFLECT, in_up=2 if hd["spec"]["up_mid"] else 1,
-                                   in_scale=sc, in_shift=sh, in_slope_t=hd["seq"][hd["pa"]].weight.detach())
+                t2[k] = ops.conv2d(normed[k], self._pk(f"{hd['name']}.{hd['ib']}", hd["cb"]), hd["cb"].bias.detach(), stride=hd["sb"],
+                                   pad_mode=ops.PAD_REFLECT, in_up=2 if hd["spec"]["up_mid"] else 1)
         # stage 3: second convolutions
-        second = ops.conv3x3_group([conv_item(f"{heads[k]['name']}.{heads[k]['ib']}", heads[k]["cb"], normed[j],
+        second = ops.conv3x3_group([conv_item(f"{heads[k]['name']}.{heads[k]['ib']}", heads[k]["cb"], normed[k],
                                               in_up=2 if heads[k]["spec"]["up_mid"] else 1, defer_reduce=True)
-                                    for j, k in enumerate(plain)])
+                                    for k in plain])
         for j, k in enumerate(plain):
             t2[k] = second[j]
         # stage 4: final norms (+ PReLU, x2 upsample, replicated rows) into the trunk's channel slices

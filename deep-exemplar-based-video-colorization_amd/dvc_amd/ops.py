@@ -139,18 +139,33 @@ def conv_out_hw(H, W, ksize=3, stride=1, dil=1, pad=1, in_up=1, in_sub=1):
 
 def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_ZERO, in_up=1, in_sub=1,
            act=ACT_NONE, act_slope=0.0, act_slope_t=None, in_scale=None, in_shift=None, in_slope_t=None,
-           residual=None, out=None, out_batch_stride=0, cfg=-1, split_k=0, tune=True):
+           residual=None, out=None, out_batch_stride=0, cfg=-1, split_k=0, tune=True, gray_input=False):
     """dvc_conv2d.  x: [N,Cin,H,W]; w_packed: [Cin, k*k, Cout].  `out` may be a channel slice view's
     base pointer tensor (pass `out_batch_stride` in elements).  `tune=False`: the library's static plan even with the
     autotuner on (the layers of the error-aware engine map: ONE summation order, the one the parity tests see).
+    `gray_input=True` (VGG19 conv1_1 only, DVC_CONV_GRAY_INPUT): x is [N,1,H,W], the centred luminance; the three input
+    channels all read (L + 50) / 100 — gray2rgb_batch folded into the load, bit-identical to gray2rgb(x) followed by this call.
     w_packed [N, Cin, k*k, Cout]: per-image filters (DvcConvDesc.w_batch_stride) — with ksize 1 a batched GEMM
     out[n] = w_packed[n]^T x[n], one launch for the whole batch (the training-side N x N products)."""
     lib = _lib.load()
-    for t, nm in ((x, "x"), (w_packed, "w_packed"), (bias, "bias"), (in_scale, "in_scale"),
+    x_bs = 0
+    if gray_input:
+        # (the luminance plane is usually the channel-0 slice of a contiguous [N,3,H,W] Lab tensor: rows contiguous, images
+        # 3*H*W apart — the descriptor's batch stride carries that, nothing is copied)
+        assert x.dim() == 4 and x.shape[1] == 1 and w_packed.dim() == 3 and w_packed.shape[0] == 3 and cfg == -1 and split_k == 0, \
+            (x.shape, w_packed.shape)
+        if x.stride(3) != 1 or x.stride(2) != x.shape[3]:
+            x = x.contiguous()
+        x_bs = x.stride(0) if x.shape[0] > 1 else 0
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
+            raise RuntimeError("dvc_amd: `x` must be a float32 ROCm device tensor; no CPU fallback")
+    for t, nm in ((None if gray_input else x, "x"), (w_packed, "w_packed"), (bias, "bias"), (in_scale, "in_scale"),
                   (in_shift, "in_shift"), (in_slope_t, "in_slope"), (act_slope_t, "act_slope"),
                   (residual, "residual")):
         _need(t, nm)
     N, Cin, H, W = x.shape
+    if gray_input:
+        Cin, tune = 3, False
     w_bs = 0
     if w_packed.dim() == 4:
         assert w_packed.shape[0] == N, (w_packed.shape, x.shape)
@@ -164,7 +179,8 @@ def conv2d(x, w_packed, bias, *, ksize=3, stride=1, dil=1, pad=1, pad_mode=PAD_Z
     if out is None:
         out = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
     d = DvcConvDesc(N, Cin, H, W, Cout, ksize, stride, dil, pad, pad_mode, in_up, in_sub, act,
-                    float(act_slope), 1 if in_slope_t is not None else 0, cfg, split_k, 0, out_batch_stride, 0, 0, w_bs)
+                    float(act_slope), 1 if in_slope_t is not None else 0, cfg, split_k, x_bs, out_batch_stride, 0,
+                    GRAY_INPUT if gray_input else 0, w_bs)
     if residual is not None:
         assert tuple(residual.shape) == (N, Cout, OH, OW), (residual.shape, (N, Cout, OH, OW))
     if _autotune and tune and cfg == -1 and split_k == 0:
@@ -264,6 +280,7 @@ def winograd_eligible(Cin, Cout, ksize=3, stride=1, dil=1, pad=1, in_affine=Fals
 
 DEFER_REDUCE = 1     # DVC_CONV_DEFER_REDUCE
 BATCH_PLAN = 2       # DVC_CONV_BATCH_PLAN
+GRAY_INPUT = 4       # DVC_CONV_GRAY_INPUT
 _batch_plan = False
 
 
@@ -578,6 +595,19 @@ def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub
     return conv2d(x, packs("direct"), bias, dil=dil, pad=dil, pad_mode=pad_mode, in_up=in_up, in_sub=in_sub, act=act,
                   act_slope=act_slope, act_slope_t=act_slope_t, residual=residual, out=out,
                   out_batch_stride=out_batch_stride, tune=not (_conv_algo == "auto" and layer is not None and layer in direct_layers()))
+
+
+# gray2rgb_batch folded into VGG19 conv1_1's load behind warp_color (r06; DVC_GRAY_FUSION=0: the two launches, bit-identical)
+_gray_fusion = _os.environ.get("DVC_GRAY_FUSION", "1") != "0"
+
+
+def gray_fusion():
+    return _gray_fusion
+
+
+def set_gray_fusion(flag=True):
+    global _gray_fusion
+    _gray_fusion = bool(flag)
 
 
 # ---- independent layers as one launch (r06: WarpNet's four heads).  DVC_GROUP_HEADS=0: one launch per layer (A/B; results are

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 17
+#define DVC_ABI_VERSION 18
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -107,6 +107,12 @@ typedef struct DvcConvDesc {
  * summation order over input channels — hence the last-place rounding — depends on N.  Used where N images MUST run together
  * anyway: the R references of one clip (/root/reference/test.py:169-181), whose ColorVidNet recurrences advance in lock step. */
 #define DVC_CONV_BATCH_PLAN 2
+/* dvc_conv2d, the 3 -> 64 image-input layer only (VGG19 conv1_1): the stored input is ONE plane per image — the centred
+ * luminance L, x_batch_stride elements apart (0 => H*W) — and every one of the three virtual input channels reads
+ * (L + 50) / 100, i.e. gray2rgb_batch(uncenter_l(L)) (utils/util.py:63-64,97-101, FrameColor.py:9) folded into the load:
+ * bit-identical to dvc_gray2rgb followed by the plain call, one launch and a 1 MB tensor less per frame.  The input affine
+ * (vgg_preprocess) applies to that value as usual. */
+#define DVC_CONV_GRAY_INPUT 4
 
 /* Output spatial size implied by a descriptor. */
 int dvc_conv2d_out_hw(const DvcConvDesc* d, int32_t* OH, int32_t* OW);

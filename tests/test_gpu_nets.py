@@ -149,6 +149,37 @@ def test_warpnet_stages_identical_inputs(nets, weights, H, W):
         assert agree[safe].float().mean().item() > 0.995
 
 
+@pytest.mark.parametrize("H,W,N", [(216, 384, 1), (48, 80, 3), (37, 53, 2)])
+def test_vgg_gray_input_folded_into_conv1_1_is_bit_identical(nets, H, W, N):
+    """r06 (DVC_CONV_GRAY_INPUT): FrameColor.py:8-10's gray2rgb_batch(IA_l) -> vggnet(...) with the replication folded into
+    conv1_1's load: every tap bit-identical to the two-step form, for a contiguous luminance tensor and for the channel-0 slice
+    of a Lab batch (what warp_color hands over: images 3*H*W apart); and warp_color gives the same warped colours either way."""
+    from dvc_amd import ops, synth
+    from dvc_amd.frame import VGG_OUT, warp_color
+    from utils.util import gray2rgb_batch
+    vgg, warp, col = nets
+    lab = torch.cat([synth.synth_lab(1000 + i, H, W) for i in range(N)]).cuda()
+    for l in (lab[:, 0:1], lab[:, 0:1].contiguous()):
+        want = vgg(gray2rgb_batch(l), VGG_OUT, preprocess=True)
+        got = vgg.forward_gray(l, VGG_OUT)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    if H % 16 == 0 and W % 16 == 0:
+        IB = torch.cat([synth.synth_lab(2 + i, H, W) for i in range(N)]).cuda()
+        fB = vgg(ops.lab2rgb(IB, l_offset=50.0), VGG_OUT, preprocess=True)
+        outs = []
+        for flag in (True, False):
+            ops.set_gray_fusion(flag)
+            try:
+                w_, s_, fA = warp_color(lab[:, 0:1], IB, fB, vgg, warp, col, 0, temperature=1e-10)
+            finally:
+                ops.set_gray_fusion(True)
+            outs.append((w_, s_, fA))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        for a, b in zip(outs[0][2], outs[1][2]):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("H,W,N", [(216, 384, 1), (48, 80, 2), (40, 64, 1), (432, 768, 1)])
 def test_warpnet_heads_grouped_launches_are_bit_identical(nets, weights, H, W, N):
     """r06: the four heads advance stage by stage, each stage ONE launch over the independent layers
