@@ -73,18 +73,30 @@ __global__ __launch_bounds__(256) void fgs_weights_kernel(const unsigned char* _
     //   wh_t[x][y] = w((y,x),(y,x+1))   [W][H]   (last row unused) — the horizontal weights, transposed
     // scan solver (line_major == 1, r05): every line contiguous — the first array [H][W] holds the HORIZONTAL weights (row lines),
     // the second [W][H] the VERTICAL ones transposed (column lines)
-    g += (long)blockIdx.y * H * W;
-    wv += (long)blockIdx.y * H * W;
-    wh_t += (long)blockIdx.y * H * W;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
-        const int y = i / W, x = i - y * W;
-        const int c = g[i];
-        const int dn = y + 1 < H ? abs(c - (int)g[i + W]) : 0;
-        const int rt = x + 1 < W ? abs(c - (int)g[i + 1]) : 0;
-        const float wd = expf(-(float)dn * inv_sigma), wr = expf(-(float)rt * inv_sigma);
-        wv[i] = line_major ? wr : wd;
-        wh_t[(long)x * H + y] = line_major ? wd : wr;
+    // r06: a workgroup = one 32 x 32 tile; the transposed array goes through LDS so that both are written in rows (as a
+    // grid-stride loop with wh_t[x * H + y] written element by element the launch took 9.7 us at 432x768, most of it that store).
+    __shared__ float t[32][33];
+    g += (long)blockIdx.z * H * W;
+    wv += (long)blockIdx.z * H * W;
+    wh_t += (long)blockIdx.z * H * W;
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x = bx + tx;
+    for (int r = ty; r < 32; r += 8) {
+        const int y = by + r;
+        if (y < H && x < W) {
+            const int i = y * W + x;
+            const int c = g[i];
+            const int dn = y + 1 < H ? abs(c - (int)g[i + W]) : 0;
+            const int rt = x + 1 < W ? abs(c - (int)g[i + 1]) : 0;
+            const float wd = expf(-(float)dn * inv_sigma), wr = expf(-(float)rt * inv_sigma);
+            wv[i] = line_major ? wr : wd;
+            t[r][tx] = line_major ? wd : wr;
+        }
     }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (bx + r < W && by + tx < H) wh_t[(long)(bx + r) * H + by + tx] = t[tx][r];
 }
 
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int H, int W,
@@ -195,9 +207,11 @@ __global__ __launch_bounds__(64) void fgs_coeff_kernel(FgsCoeffDir d0, FgsCoeffD
 // Layout: LINE-major ([plane][line][L]: a line is contiguous, lane j of the wave loads element k * 64 + j, coalesced) with the
 // blocked re-distribution (lane j owns elements j E .. j E + E - 1) through LDS at an odd pitch (conflict-free).
 template <int E>
-__global__ __launch_bounds__(256) void fgs_solve_scan_kernel(float* __restrict__ f, const float* __restrict__ ap,
+__global__ __launch_bounds__(256) void fgs_solve_scan_kernel(const float* fin, float* f, const float* __restrict__ ap,
                                                             const float* __restrict__ inv, const float* __restrict__ cp, int L,
                                                             int nlines, int planes_per_guide) {
+    // (fin: where the lines are read — f itself, or for the first sweep of a filter the caller's source image: r06, the copy
+    // dst <- src that used to precede the sweeps is gone)
     constexpr int EP = E | 1;
     __shared__ float sA[4][64 * EP], sG[4][64 * EP], sC[4][64 * EP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -207,13 +221,14 @@ __global__ __launch_bounds__(256) void fgs_solve_scan_kernel(float* __restrict__
     const int plane = blockIdx.y;
     const long goff = ((long)(plane / planes_per_guide) * nlines + line) * L;
     float* fp = f + ((long)plane * nlines + line) * L;
+    const float* fip = fin + ((long)plane * nlines + line) * L;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
         const int p = k * 64 + lane;
         float a = 0.f, g = 0.f, c = 0.f;
         if (p < L) {
             a = ap[goff + p];
-            g = fp[p] * inv[goff + p];
+            g = fip[p] * inv[goff + p];
             c = cp[goff + p];
         }
         const int q = (p / E) * EP + (p % E);
@@ -486,10 +501,10 @@ static void fgs_coeff_window(hipStream_t s, const float* w, int L, int nlines, i
 #undef FGS_CWIN
 }
 
-static void fgs_solve_scan(hipStream_t s, float* f, const float* ap, const float* inv, const float* cp, int L, int nlines, int planes,
-                           int planes_per_guide) {
+static void fgs_solve_scan(hipStream_t s, const float* fin, float* f, const float* ap, const float* inv, const float* cp, int L, int nlines,
+                           int planes, int planes_per_guide) {
     const dim3 grid(cdiv(nlines, 4), planes);
-#define FGS_SCAN(E_) case E_: hipLaunchKernelGGL((fgs_solve_scan_kernel<E_>), grid, dim3(256), 0, s, f, ap, inv, cp, L, nlines, planes_per_guide); break;
+#define FGS_SCAN(E_) case E_: hipLaunchKernelGGL((fgs_solve_scan_kernel<E_>), grid, dim3(256), 0, s, fin, f, ap, inv, cp, L, nlines, planes_per_guide); break;
     switch (cdiv(L, 64)) {
         FGS_SCAN(1) FGS_SCAN(2) FGS_SCAN(3) FGS_SCAN(4) FGS_SCAN(5) FGS_SCAN(6) FGS_SCAN(7) FGS_SCAN(8)
         FGS_SCAN(9) FGS_SCAN(10) FGS_SCAN(11) FGS_SCAN(12) FGS_SCAN(13) FGS_SCAN(14) FGS_SCAN(15) FGS_SCAN(16)
@@ -650,10 +665,10 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
     const bool window = scan && warm_max <= FGS_WARM_MAX;
     if (!window && !room2) scan = false;        // (one coefficient copy only: the thread-per-line solver reads it where it is)
     // (windowed coefficients: wv = the horizontal weights [H][W], wh_t = the vertical ones transposed [W][H]: every line contiguous)
-    hipLaunchKernelGGL(fgs_weights_kernel, dim3(cdiv((int)HW, 1024), n_guides), dim3(256), 0, s, guide, H, W,
+    hipLaunchKernelGGL(fgs_weights_kernel, dim3(cdiv(W, 32), cdiv(H, 32), n_guides), dim3(256), 0, s, guide, H, W,
                        1.0f / sigma_color, wv, wh_t, window ? 1 : 0);
     DVC_CHECK_LAUNCH("dvc_fgs_filter(weights)");
-    if (dst != src) {
+    if (dst != src && !scan) {     // (the scan solver's first row sweep reads src itself)
         hipError_t e = hipMemcpyAsync(dst, src, sizeof(float) * planes * HW, hipMemcpyDeviceToDevice, s);
         DVC_REQUIRE(e == hipSuccess, "dvc_fgs_filter: copy failed: %s", hipGetErrorString(e));
     }
@@ -680,7 +695,7 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
     for (int it = 0; it < num_iter; ++it) {
         if (scan) {
             // rows in place on the image; columns on the transposed image
-            fgs_solve_scan(s, dst, row_lm + 2 * IT + it * GHW, row_lm + IT + it * GHW, row_lm + it * GHW, W, H, planes, planes_per_guide);
+            fgs_solve_scan(s, it == 0 ? src : dst, dst, row_lm + 2 * IT + it * GHW, row_lm + IT + it * GHW, row_lm + it * GHW, W, H, planes, planes_per_guide);
             // columns in place too (r06): 16-column tiles through LDS instead of a transposed copy of the image
             fgs_solve_scan_cols(s, dst, col_lm + 2 * IT + it * GHW, col_lm + IT + it * GHW, col_lm + it * GHW, H, W, planes, planes_per_guide);
         } else {
@@ -700,33 +715,123 @@ extern "C" int dvc_fgs_filter(const uint8_t* guide, const float* src, int32_t n_
 
 // ---- batch_lab2rgb_transpose_mc (utils/util.py:134-151) for one image: skimage.color.lab2rgb in float64,
 // clip, * 255, astype(uint8); output HWC.
-__global__ __launch_bounds__(256) void lab2rgb_u8_kernel(const float* __restrict__ L, const float* __restrict__ ab,
-                                                         long HW, unsigned char* __restrict__ rgb) {
+// r06: two tiers.  As one float64 chain per pixel the launch took 15.5 us at 432x768 — three float64 pow() per pixel, the
+// chip's float64 rate.  What is needed of the float64 value v * 255 is only its integer part; a float32 evaluation t of the same
+// chain is within  delta = 0.004 S + 0.002  of it, S = the sum of the magnitudes of the three terms of the matrix row (rounding of
+// the terms and of their sum ~1.2e-6 S, amplified by at most 12.92 — the slope of the sRGB curve at its steepest, the linear
+// piece — times 255; measured over 2e7 random Lab triples: 0.0041 where S <= 5.2; the two piecewise functions are continuous
+// at their thresholds to 1e-7, so a different branch in the two evaluations is inside the same bound).  A channel whose t is
+// further than delta from every integer (and from the clipping points) is final; a channel closer than that — a few per cent of
+// them, and every NaN — is queued in LDS and the workgroup evaluates the queue in float64 with all lanes busy.
+// The bytes written are those of the float64 chain in every case (tests/test_tail.py: bit-exact against the oracle).
+// one channel of one pixel, float64 (the reference chain)
+__device__ __forceinline__ unsigned char lab2rgb_ch_f64(double l_c, double a, double b, int k) {
     // inverse of skimage's xyz_from_rgb (its rgb_from_xyz = scipy.linalg.inv(xyz_from_rgb), float64)
-    const double M[3][3] = {{3.240481343200526, -1.5371515162713185, -0.4985363261688878},
-                            {-0.9692549499965682, 1.8759900014898907, 0.04155592655829284},
-                            {0.05564663913517716, -0.20404133836651123, 1.0573110696453443}};
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
-        const double l = (double)L[i] + 50.0, a = (double)ab[i], b = (double)ab[HW + i];
-        const double fy = (l + 16.0) / 116.0;
-        const double fx = a / 500.0 + fy;
-        double fz = fy - b / 200.0;
-        fz = fz < 0.0 ? 0.0 : fz;
-        double xyz[3] = {fx, fy, fz};
+    const double m0 = k == 0 ? 3.240481343200526 : k == 1 ? -0.9692549499965682 : 0.05564663913517716;
+    const double m1 = k == 0 ? -1.5371515162713185 : k == 1 ? 1.8759900014898907 : -0.20404133836651123;
+    const double m2 = k == 0 ? -0.4985363261688878 : k == 1 ? 0.04155592655829284 : 1.0573110696453443;
+    const double l = l_c + 50.0;
+    const double fy = (l + 16.0) / 116.0;
+    const double fx = a / 500.0 + fy;
+    double fz = fy - b / 200.0;
+    fz = fz < 0.0 ? 0.0 : fz;
+    double xyz[3] = {fx, fy, fz};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double v = xyz[k];
-            xyz[k] = v > 0.2068966 ? v * v * v : (v - 16.0 / 116.0) / 7.787;
-        }
-        xyz[0] *= 0.95047;
-        xyz[2] *= 1.08883;
+    for (int c = 0; c < 3; ++c) {
+        const double v = xyz[c];
+        xyz[c] = v > 0.2068966 ? v * v * v : (v - 16.0 / 116.0) / 7.787;
+    }
+    xyz[0] *= 0.95047;
+    xyz[2] *= 1.08883;
+    double v = xyz[0] * m0 + xyz[1] * m1 + xyz[2] * m2;
+    v = v > 0.0031308 ? 1.055 * pow(v, 1.0 / 2.4) - 0.055 : v * 12.92;
+    v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    return (unsigned char)(int)(v * 255.0);
+}
+
+// float32 tier: the decided bytes in out[0..2] (0 where undecided), returns the mask of the UNDECIDED channels
+__device__ __forceinline__ unsigned lab2rgb_px_f32(float l_c, float a, float b, unsigned char* out) {
+    const float M[3][3] = {{3.240481343200526f, -1.5371515162713185f, -0.4985363261688878f},
+                           {-0.9692549499965682f, 1.8759900014898907f, 0.04155592655829284f},
+                           {0.05564663913517716f, -0.20404133836651123f, 1.0573110696453443f}};
+    const float l = l_c + 50.f;
+    const float fy = (l + 16.f) / 116.f;
+    const float fx = a / 500.f + fy;
+    float fz = fy - b / 200.f;
+    fz = fz < 0.f ? 0.f : fz;
+    float xyz[3] = {fx, fy, fz};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            double v = xyz[0] * M[k][0] + xyz[1] * M[k][1] + xyz[2] * M[k][2];
-            v = v > 0.0031308 ? 1.055 * pow(v, 1.0 / 2.4) - 0.055 : v * 12.92;
-            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
-            rgb[3 * i + k] = (unsigned char)(int)(v * 255.0);
+    for (int k = 0; k < 3; ++k) {
+        const float v = xyz[k];
+        xyz[k] = v > 0.2068966f ? v * v * v : (v - 16.f / 116.f) / 7.787f;
+    }
+    xyz[0] *= 0.95047f;
+    xyz[2] *= 1.08883f;
+    unsigned undecided = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float t0 = xyz[0] * M[k][0], t1 = xyz[1] * M[k][1], t2 = xyz[2] * M[k][2];
+        float v = t0 + t1 + t2;
+        const float delta = 0.004f * (fabsf(t0) + fabsf(t1) + fabsf(t2)) + 0.002f;
+        v = v > 0.0031308f ? 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (1.f / 2.4f)) - 0.055f : v * 12.92f;
+        const float t = v * 255.f;
+        out[k] = 0;
+        if (t <= -delta) out[k] = 0;
+        else if (t >= 255.f + delta) out[k] = 255;
+        else {
+            const float fl = floorf(t), q = t - fl;
+            // (written so that a NaN anywhere fails the test; t in [-delta, delta] or [255 - delta, 255 + delta] fails it as well)
+            if (t >= delta && t <= 255.f - delta && q >= delta && q <= 1.f - delta) out[k] = (unsigned char)(int)fl;
+            else undecided |= 1u << k;
         }
+    }
+    return undecided;
+}
+
+// A workgroup = 1024 consecutive pixels, a thread = 4 consecutive ones (12 output bytes = three aligned words).  Undecided
+// CHANNELS (not pixels: one float64 pow per entry, the latency of the second phase is one pow) are queued in LDS; their bytes
+// are written after the barrier, over the placeholder the word stores put there.
+__global__ __launch_bounds__(256) void lab2rgb_u8_kernel(const float* __restrict__ L, const float* __restrict__ ab,
+                                                         long HW, unsigned char* rgb) {
+    __shared__ int queue[3 * 1024];
+    __shared__ int qn;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    const long base = (long)blockIdx.x * 1024;
+    const long i0 = base + 4 * threadIdx.x;
+    union { unsigned char b[12]; unsigned w[3]; } out;
+    unsigned und = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long i = i0 + j;
+        out.b[3 * j] = out.b[3 * j + 1] = out.b[3 * j + 2] = 0;
+        if (i < HW) und |= lab2rgb_px_f32(L[i], ab[i], ab[HW + i], out.b + 3 * j) << (3 * j);
+    }
+    if (i0 + 3 < HW && (reinterpret_cast<uintptr_t>(rgb) & 3) == 0) {
+        unsigned* wp = reinterpret_cast<unsigned*>(rgb + 3 * i0);
+        wp[0] = out.w[0]; wp[1] = out.w[1]; wp[2] = out.w[2];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < HW) {
+                rgb[3 * (i0 + j) + 0] = out.b[3 * j + 0];
+                rgb[3 * (i0 + j) + 1] = out.b[3 * j + 1];
+                rgb[3 * (i0 + j) + 2] = out.b[3 * j + 2];
+            }
+    }
+    if (und) {
+        const int cnt = __popc(und);
+        int at = atomicAdd(&qn, cnt);
+#pragma unroll
+        for (int e = 0; e < 12; ++e)
+            if (und & (1u << e)) queue[at++] = (4 * threadIdx.x + e / 3) * 4 + e % 3;
+    }
+    __syncthreads();
+    const int n = qn;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int ent = queue[e], k = ent & 3;
+        const long i = base + (ent >> 2);
+        rgb[3 * i + k] = lab2rgb_ch_f64((double)L[i], (double)ab[i], (double)ab[HW + i], k);
     }
 }
 extern "C" int dvc_lab2rgb_u8(const float* L_centered, const float* ab, int32_t H, int32_t W, uint8_t* rgb_hwc,

@@ -234,6 +234,32 @@ def test_gpu_clip_rgb_equals_stagewise():
 
 
 @pytest.mark.gpu
+def test_gpu_lab_to_rgb8_two_tier_is_the_float64_chain_byte_for_byte():
+    """dvc_lab2rgb_u8 (r06): a float32 evaluation decides the bytes that are further than its error bound from a rounding
+    boundary, the rest of the pixels go through the float64 chain.  Byte-for-byte the oracle's float64 result on 3.1 million
+    pixels: in-gamut colours, far out-of-gamut ones (both clipping points, the linear pieces of both curves), a dense grey
+    ramp (every channel crosses all 255 boundaries), and exact zeros."""
+    from dvc_amd import tail
+    rng = np.random.default_rng(11)
+    H, W = 1024, 1024
+    L = rng.uniform(-50, 50, (H, W)).astype(np.float32)
+    ab = rng.uniform(-110, 110, (2, H, W)).astype(np.float32)
+    L2 = rng.uniform(-80, 90, (H, W)).astype(np.float32)            # beyond the gamut: negative and > 1 linear values
+    ab2 = (rng.standard_normal((2, H, W)) * 150).astype(np.float32)
+    L3 = np.linspace(-50, 50, H * W, dtype=np.float32).reshape(H, W)
+    ab3 = np.zeros((2, H, W), np.float32)
+    ab3[:, H // 2:] = rng.uniform(-3, 3, (2, H - H // 2, W)).astype(np.float32)
+    for Lc, abc in ((L, ab), (L2, ab2), (L3, ab3)):
+        got = tail.lab_to_rgb8(torch.from_numpy(Lc).cuda(), torch.from_numpy(abc).cuda()).cpu().numpy()
+        ref = T.lab_to_rgb8(Lc, abc)
+        assert got.shape == ref.shape == (H, W, 3)
+        assert np.array_equal(got, ref), int((got != ref).sum())
+    # ragged size (not a multiple of the 1024 pixels a workgroup takes)
+    got = tail.lab_to_rgb8(torch.from_numpy(L[:37, :53].copy()).cuda(), torch.from_numpy(ab[:, :37, :53].copy()).cuda()).cpu().numpy()
+    assert np.array_equal(got, T.lab_to_rgb8(L[:37, :53], ab[:, :37, :53]))
+
+
+@pytest.mark.gpu
 def test_gpu_rgb8_to_lab_matches_oracle_and_round_trips():
     from dvc_amd import tail
     rng = np.random.default_rng(2)
