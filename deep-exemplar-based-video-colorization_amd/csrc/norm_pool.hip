@@ -55,7 +55,22 @@ __device__ __forceinline__ void plane_stats(const float* __restrict__ xp, int HW
     for (int k = 0; k < 4; ++k) {
         if (k < nv) {
             const int v = tid + k * nt;
-            for (int i = v * 4; i < HW4; i += VT * 4) {
+            int i = v * 4;
+            // (r06: four pieces in flight per virtual thread, accumulated in the same order as one at a time — as a plain loop
+            // the compiler waits for every load before it issues the next.  Four, not eight: the kernels that call this must stay
+            // under 64 VGPRs, two 1024-thread workgroups per CU — eight cost the grouped launch 4 us)
+            for (; i + 3 * VT * 4 < HW4; i += 4 * VT * 4) {
+                float4 x8[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x8[u] = *reinterpret_cast<const float4*>(xp + i + u * (VT * 4));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double a = x8[u].x, b = x8[u].y, cc = x8[u].z, d = x8[u].w;
+                    s[k] += (a + b) + (cc + d);
+                    q[k] += (a * a + b * b) + (cc * cc + d * d);
+                }
+            }
+            for (; i < HW4; i += VT * 4) {
                 float4 x4 = *reinterpret_cast<const float4*>(xp + i);
                 double a = x4.x, b = x4.y, cc = x4.z, d = x4.w;
                 s[k] += (a + b) + (cc + d);
@@ -170,18 +185,32 @@ __device__ __forceinline__ void instnorm_apply_plane(const float* xp, const int 
         const bool v4 = ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp) |
                           reinterpret_cast<uintptr_t>(rp)) & 15) == 0;
         const int T4 = v4 ? (total & ~3) : 0;
-        for (int i = threadIdx.x * 4; i < T4; i += nt * 4) {
-            float4 v = *reinterpret_cast<const float4*>(xp + i);
+        auto piece = [&](const float4& v, const float4& r, int i) {
             float o[4] = {v.x * sc + sh, v.y * sc + sh, v.z * sc + sh, v.w * sc + sh};
-            if (rp) {
-                float4 r = *reinterpret_cast<const float4*>(rp + i);
-                o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
-            }
+            if (rp) { o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
             if (has_act) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = o[k] >= 0.f ? o[k] : o[k] * slope;
             }
             *reinterpret_cast<float4*>(yp + i) = make_float4(o[0], o[1], o[2], o[3]);
+        };
+        int i = threadIdx.x * 4;
+        // (two pieces in flight per thread — elementwise, so the order is immaterial; in place each thread reads its two
+        // pieces before it writes either, and no other thread touches them)
+        for (; i + nt * 4 < T4; i += 2 * nt * 4) {
+            float4 v[2], r[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                v[u] = *reinterpret_cast<const float4*>(xp + i + u * nt * 4);
+                r[u] = rp ? *reinterpret_cast<const float4*>(rp + i + u * nt * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) piece(v[u], r[u], i + u * nt * 4);
+        }
+        for (; i < T4; i += nt * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + i);
+            const float4 r = rp ? *reinterpret_cast<const float4*>(rp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            piece(v, r, i);
         }
         for (int i = T4 + threadIdx.x; i < total; i += nt) {
             float v = xp[i] * sc + sh;
@@ -639,14 +668,29 @@ __global__ __launch_bounds__(256) void channel_l2norm_multi_kernel(L2MultiArgs a
     float* yn = a.y[ti] + (long)n * C * HW;
     const bool ok = p < HW;  // HW % 4 == 0
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok)
-        for (int c = g; c < C; c += 32) {
+    if (ok) {
+        int c = g;
+        // (r06: four channel rows in flight per thread, accumulated in the same order as one at a time)
+        for (; c + 96 < C; c += 128) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xn + (long)(c + 32 * u) * HW + p);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s.x = fmaf(v[u].x, v[u].x, s.x);
+                s.y = fmaf(v[u].y, v[u].y, s.y);
+                s.z = fmaf(v[u].z, v[u].z, s.z);
+                s.w = fmaf(v[u].w, v[u].w, s.w);
+            }
+        }
+        for (; c < C; c += 32) {
             const float4 v = *reinterpret_cast<const float4*>(xn + (long)c * HW + p);
             s.x = fmaf(v.x, v.x, s.x);
             s.y = fmaf(v.y, v.y, s.y);
             s.z = fmaf(v.z, v.z, s.z);
             s.w = fmaf(v.w, v.w, s.w);
         }
+    }
     part[g][px4] = s;
     __syncthreads();
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -656,12 +700,24 @@ __global__ __launch_bounds__(256) void channel_l2norm_multi_kernel(L2MultiArgs a
         t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
     const float4 den = make_float4(sqrtf(t.x) + a.eps, sqrtf(t.y) + a.eps, sqrtf(t.z) + a.eps, sqrtf(t.w) + a.eps);
-    if (ok)
-        for (int c = g; c < C; c += 32) {
+    if (ok) {
+        int c = g;
+        for (; c + 96 < C; c += 128) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(xn + (long)(c + 32 * u) * HW + p);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u].x /= den.x; v[u].y /= den.y; v[u].z /= den.z; v[u].w /= den.w;
+                *reinterpret_cast<float4*>(yn + (long)(c + 32 * u) * HW + p) = v[u];
+            }
+        }
+        for (; c < C; c += 32) {
             float4 v = *reinterpret_cast<const float4*>(xn + (long)c * HW + p);
             v.x /= den.x; v.y /= den.y; v.z /= den.z; v.w /= den.w;
             *reinterpret_cast<float4*>(yn + (long)c * HW + p) = v;
         }
+    }
 }
 
 extern "C" int dvc_channel_l2norm_multi(const float* const* x, float* const* y, const int32_t* C, const int32_t* HW,
