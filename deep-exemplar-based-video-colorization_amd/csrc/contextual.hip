@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void cx_ds_kernel(const float* __restrict__ S,
         if (tt) { tt += b * tq_bs; qq += b * tq_bs; }
         gscale += b;
         if (dS) dS += b * S_bs;
-        dST += b * (long)N * ldt;
+        if (dST) dST += b * (long)N * ldt;
     }
     const float g = *gscale * gout;
     const int cj = (mode == 1 && jok) ? cargi[j] : -1;
@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void cx_ds_kernel(const float* __restrict__ S,
         }
         tile[il][tx] = v;
     }
+    if (!dST) return;       // (uniform: row-major only — the caller's GEMM takes dS transposed as it is)
     __syncthreads();
     const int i = ib + tx;
 #pragma unroll 4
@@ -304,7 +305,7 @@ extern "C" int dvc_cx_ds(const float* S, int32_t nb, int64_t S_bs, int64_t row_b
                          const float* r, const float* e, const int32_t* jstar, const int32_t* cargi, const float* t, const float* q,
                          const float* gscale, float gout, int32_t mode, int32_t rows, int32_t N, int32_t row0, int32_t ld_t, float h,
                          float* dS, float* dST, dvcStream stream) {
-    DVC_REQUIRE(S && a && l && r && e && jstar && gscale && dST && nb > 0 && nb < 65536 && rows > 0 && N > 0 && ld_t >= rows && h > 0.f,
+    DVC_REQUIRE(S && a && l && r && e && jstar && gscale && (dS || dST) && nb > 0 && nb < 65536 && rows > 0 && N > 0 && ld_t >= rows && h > 0.f,
                 "dvc_cx_ds: bad argument");
     DVC_REQUIRE(mode == 0 || (mode == 1 && cargi && t && q), "dvc_cx_ds: mode 1 needs the column arg-max and the T / Q row sums");
     hipLaunchKernelGGL(cx_ds_kernel, dim3(cdiv(N, 64), cdiv(ld_t, 64), nb), dim3(256), 0, (hipStream_t)stream, S, a, l, r, e, jstar,

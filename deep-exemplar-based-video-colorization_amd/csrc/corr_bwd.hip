@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void corr_bwd_ds_kernel(const float* __restric
         const long bz = blockIdx.z;
         F += bz * ldt * P;
         dS += bz * ldt * P;
-        dST += bz * (long)P * ldt;
+        if (dST) dST += bz * (long)P * ldt;
         blab += bz * 3 * P;
         gy += bz * 3 * cs;
         y += bz * 3 * cs;
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void corr_bwd_ds_kernel(const float* __restric
         }
         tile[il][tx] = v;
     }
+    if (!dST) return;           // (uniform: the caller multiplies with dS^T through a GEMM that takes the operand transposed)
     __syncthreads();
     // transposed copy: thread (tx -> row i0 + tx, ty -> 16 columns)
     const int i = i0 + tx;
@@ -130,7 +131,7 @@ extern "C" int dvc_corr_softmax_bwd(const float* f_blk, const float* blab, const
                                     const float* sim, const float* gsim, const int32_t* argmax, float temperature,
                                     float wta_scale, int32_t batch, int32_t rows, int32_t P, int64_t chan_stride, int32_t ld_t,
                                     float* rowstat_scratch, float* dS, float* dST, dvcStream stream) {
-    DVC_REQUIRE(f_blk && blab && gy && y && rowstat_scratch && dS && dST, "dvc_corr_softmax_bwd: null argument");
+    DVC_REQUIRE(f_blk && blab && gy && y && rowstat_scratch && dS, "dvc_corr_softmax_bwd: null argument");
     (void)sim;
     float* rowmax = rowstat_scratch;
     float* lsum_scratch = rowstat_scratch + ld_t;

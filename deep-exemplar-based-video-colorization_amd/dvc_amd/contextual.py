@@ -74,13 +74,20 @@ class _ContextualCX(torch.autograd.Function):
         hy, wy = (Y.shape[2], Y.shape[3]) if Y.dim() == 4 else (1, Ny)
         # r04: the whole batch per launch — S[b] = Xn[b]^T Yn[b] is a 1x1 convolution with PER-IMAGE filters (a batched GEMM,
         # DvcConvDesc.w_batch_stride) and the row / column kernels take the batch as a grid dimension
-        S = torch.empty((B, R, hy, wy), **f32)
-        blk = torch.zeros((B, C, 1, R), **f32)           # K-major blocks of Xn columns (one buffer for every block)
+        lib_gemm = ops.gemm_lib()     # r06: S through the vendor's batched GEMM (ops.bmm), no staging copy, no padded rows
+        S = None if lib_gemm else torch.empty((B, R, hy, wy), **f32)
+        blk = None if lib_gemm else torch.zeros((B, C, 1, R), **f32)           # K-major blocks of Xn columns (one buffer for every block)
         y_img = Yn.view(B, C, hy, wy)
         S_bs = R * Ny
+        Sbuf = {}
         for i0 in range(0, Nx, R):
             rows = min(R, Nx - i0)
-            _s_block(Xn, y_img, i0, rows, R, S, blk)
+            if lib_gemm:
+                S = Sbuf.setdefault(rows, torch.empty((B, rows, Ny), **f32))
+                S_bs = rows * Ny
+                ops.bmm(Xn[:, :, i0:i0 + rows].transpose(1, 2), Yn, out=S)
+            else:
+                _s_block(Xn, y_img, i0, rows, R, S, blk)
             sl = slice(i0, i0 + rows)
             _lib.check(lib.dvc_cx_rows(_p(S), B, S_bs, Nx, rows, Ny, float(h), _p(a[:, sl]), _ip(jstar[:, sl]), _p(l[:, sl]),
                                        _p(r[:, sl]), _p(e[:, sl]), st), "dvc_cx_rows")
@@ -110,12 +117,34 @@ class _ContextualCX(torch.autograd.Function):
         # no host read-back, the backward pass only enqueues
         gs = (gscale * gout.detach().to(gscale.dtype)).contiguous()
         R = _row_block(B, Nx, Ny)
-        S = torch.empty((B, R, hy, wy), **f32)
-        blk = torch.zeros((B, C, 1, R), **f32)
-        dST = torch.empty((B, Ny, R // 32, 32), **f32)                       # [Ny][R] per image, as an image of R "pixels"
+        lib_gemm = ops.gemm_lib()     # r06: both products through the vendor's batched GEMM (ops.bmm); dS row-major only
         tt, qq = (torch.empty((B, R), **f32), torch.empty((B, R), **f32)) if mode == 1 else (None, None)
         dXn = torch.empty_like(Xn)
         y_img = Yn.view(B, C, hy, wy)
+        if lib_gemm:
+            bufs = {}
+            for i0 in range(0, Nx, R):
+                rows = min(R, Nx - i0)
+                if rows not in bufs:
+                    bufs[rows] = (torch.empty((B, rows, Ny), **f32), torch.empty((B, rows, Ny), **f32), torch.empty((B, C, rows), **f32))
+                S, dS, dxb = bufs[rows]
+                S_bs = rows * Ny
+                ops.bmm(Xn[:, :, i0:i0 + rows].transpose(1, 2), Yn, out=S)
+                sl = slice(i0, i0 + rows)
+                if mode == 1:
+                    _lib.check(lib.dvc_cx_rows_tq(_p(S), B, S_bs, Nx, R, _p(a[:, sl]), _p(l[:, sl]), _ip(cargi), rows, Ny, i0, h, _p(tt),
+                                                  _p(qq), st), "dvc_cx_rows_tq")
+                _lib.check(lib.dvc_cx_ds(_p(S), B, S_bs, Nx, R, _p(a[:, sl]), _p(l[:, sl]), _p(r[:, sl]), _p(e[:, sl]), _ip(jstar[:, sl]),
+                                         None if cargi is None else _ip(cargi), _p(tt), _p(qq), _p(gs), 1.0, mode, rows, Ny, i0, rows, h,
+                                         _p(dS), None, st), "dvc_cx_ds")
+                ops.bmm(Yn, dS.transpose(1, 2), out=dxb)                      # d Xn[b, c, i0 + i] = sum_j Yn[b, c, j] dS[b, i, j]
+                dXn[:, :, i0:i0 + rows] = dxb
+            dX = torch.empty_like(Xn)
+            _lib.check(lib.dvc_cx_normalize_bwd(_p(Xn), _p(normX), _p(dXn), B, C, Nx, float(EPS64), _p(dX), st), "dvc_cx_normalize_bwd")
+            return dX.view(xshape), None, None, None, None
+        S = torch.empty((B, R, hy, wy), **f32)
+        blk = torch.zeros((B, C, 1, R), **f32)
+        dST = torch.empty((B, Ny, R // 32, 32), **f32)                       # [Ny][R] per image, as an image of R "pixels"
         y_t = Yn.transpose(1, 2).contiguous().view(B, Ny, 1, C)              # K-major per-image filters of d Xn = Yn dS^T
         S_bs = R * Ny
         for i0 in range(0, Nx, R):

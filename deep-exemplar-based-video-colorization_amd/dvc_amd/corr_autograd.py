@@ -6,9 +6,12 @@ forward is the fused HIP kernel (dvc_corr_fwd) and the backward recomputes the a
 keeping the P x P matrices autograd would have saved (4 x 107 MB per image at 216x384):
 
     for each block of R query rows:
-        F      = theta_blk^T phi                                   1x1-convolution engine   [R, P]
-        dS     = p (g.B_j - g.y_i) / T  (+ d sim at the arg-max)   dvc_corr_softmax_bwd     [R, P] and [P, R]
-        d phi += theta_blk dS ;  d theta_blk = phi dS^T            1x1-convolution engine
+        F      = theta_blk^T phi                                   batched GEMM             [R, P]
+        dS     = p (g.B_j - g.y_i) / T  (+ d sim at the arg-max)   dvc_corr_softmax_bwd     [R, P] (and [P, R] for the engine)
+        d phi += theta_blk dS ;  d theta_blk = phi dS^T            batched GEMMs
+
+The three products are plain fp32 GEMMs: the vendor's batched GEMM by default (r06, ops.bmm), this library's 1x1-convolution
+engine with per-image filters under DVC_GEMM_LIB=0 (r04-r05).
 
 Gradients flow to theta and phi (the centred, normalised projections); the pooled exemplar colours are data (no
 gradient).  r05: the WTA re-weighting (`WTA_scale_weight != 1`, NonlocalNet.py:288-327; dead in both reference drivers) is
@@ -61,6 +64,8 @@ class _FusedCorrelation(torch.autograd.Function):
         if (P * C) % 4 or (C * R) % 4:
             chunk = 1               # (per-image filter slices must be 16-byte aligned)
         f32 = dict(device=dev, dtype=torch.float32)
+        if ops.gemm_lib():
+            return _backward_gemm_lib(ctx, theta, phi, blab, y, sim, amax, gy, gsim_c, need_sim, d_theta, d_phi, R)
         F = torch.empty((chunk, R, h, w), **f32)
         dS = torch.empty((chunk, R, h, w), **f32)
         dST = torch.empty((chunk, P, R // 32, 32), **f32)            # [P][R] per image, as an image of R "pixels"
@@ -100,6 +105,42 @@ class _FusedCorrelation(torch.autograd.Function):
                 dth = ops.conv2d(dSTb, phi_t, None, ksize=1, pad=0)          # [nb, C, R/32, 32]
                 d_theta[sl_b, :, i0:i0 + rows] = dth.view(nb, C, R)[:, :, :rows]
         return d_theta, d_phi, None, None, None, None, None
+
+
+def _backward_gemm_lib(ctx, theta, phi, blab, y, sim, amax, gy, gsim_c, need_sim, d_theta, d_phi, R):
+    """r06: the same block loop with the three products on the vendor's batched GEMM (ops.bmm: 103-121 TFLOP/s against the 1x1
+    engine's 77-81 on these shapes).  theta's column block and dS go in as views (no staging copies, no zero padding of the
+    last block, no transposed copy of dS: dvc_corr_softmax_bwd(dST = NULL)); d phi accumulates in place (beta = 1)."""
+    T = ctx.temperature
+    B, C, P = theta.shape
+    lib = _lib.load()
+    f32 = dict(device=theta.device, dtype=torch.float32)
+    chunk = max(1, min(B, BLOCK_BYTES // (4 * R * P)))
+    lsum = torch.empty(chunk * 3 * R, **f32)
+    yv, gyv, blv, amv = y.view(B, 3, P), gy.view(B, 3, P), blab.view(B, 3, P), amax.view(B, P)
+    bufs = {}
+    for b0 in range(0, B, chunk):
+        nb = min(chunk, B - b0)
+        sl_b = slice(b0, b0 + nb)
+        for i0 in range(0, P, R):
+            rows = min(R, P - i0)
+            if (nb, rows) not in bufs:
+                bufs[(nb, rows)] = (torch.empty((nb, rows, P), **f32), torch.empty((nb, rows, P), **f32), torch.empty((nb, C, rows), **f32))
+            Fb, dSb, dth = bufs[(nb, rows)]
+            th_blk = theta[sl_b, :, i0:i0 + rows]                      # [nb, C, rows] view
+            ops.bmm(th_blk.transpose(1, 2), phi[sl_b], out=Fb)         # F[b, i, :] = sum_c theta[b, c, i0 + i] phi[b, c, :]
+            off = 4 * i0
+            rc = lib.dvc_corr_softmax_bwd(
+                _p(Fb), _p(blv[sl_b]), ctypes.c_void_p(gyv[sl_b].data_ptr() + off), ctypes.c_void_p(yv[sl_b].data_ptr() + off),
+                ctypes.c_void_p(sim.view(B, P)[sl_b].data_ptr() + off),
+                ctypes.c_void_p(gsim_c[sl_b].data_ptr() + off) if need_sim else None,
+                ctypes.c_void_p(amv[sl_b].data_ptr() + off) if need_sim else None,
+                T, ctx.wta, nb, rows, P, P, rows, _p(lsum), _p(dSb), None, _stream())
+            _lib.check(rc, "dvc_corr_softmax_bwd")
+            ops.bmm(th_blk, dSb, out=d_phi[sl_b], accumulate=True)     # d phi[b, c, j] += sum_i theta[b, c, i0 + i] dS[b, i, j]
+            ops.bmm(phi[sl_b], dSb.transpose(1, 2), out=dth)           # d theta[b, c, i0 + i] = sum_j phi[b, c, j] dS[b, i, j]
+            d_theta[sl_b, :, i0:i0 + rows] = dth
+    return d_theta, d_phi, None, None, None, None, None
 
 
 def fused_correlation(theta, phi, B_lab_pooled, temperature, h, w, WTA_scale_weight=1):

@@ -597,6 +597,40 @@ def conv3x3(x, weight, packs, bias, *, dil=1, pad_mode=PAD_ZERO, in_up=1, in_sub
                   out_batch_stride=out_batch_stride, tune=not (_conv_algo == "auto" and layer is not None and layer in direct_layers()))
 
 
+# ---- the training side's plain batched GEMMs (r06).  The three recompute products of the fused correlation's backward and the
+# N x N products of the contextual losses are plain fp32 GEMMs with nothing fused into them; the vendor's library
+# (rocBLAS / hipBLASLt behind torch.bmm: fp32 MFMA, exact products, fp32 accumulation — torch's float32 matmul precision is
+# "highest" on ROCm and is asserted below) runs them at 103-121 TFLOP/s on the MI355X where this library's 1x1-convolution
+# engine reaches 77-81 (tools/gemm_lib_probe.py; the engine keeps the better rounding: blocked sums, 2e-7 against 9e-7 of
+# the result's scale — both far inside the tolerances of tests/test_gpu_corr_backward.py).  DVC_GEMM_LIB=0 / set_gemm_lib(False)
+# keeps every product on the engine.  The INFERENCE path never comes here.
+_gemm_lib = _os.environ.get("DVC_GEMM_LIB", "1") != "0"
+
+
+def gemm_lib():
+    return _gemm_lib
+
+
+def set_gemm_lib(flag=True):
+    global _gemm_lib
+    _gemm_lib = bool(flag)
+
+
+def bmm(a, b, out=None, accumulate=False):
+    """out = a @ b (or out += a @ b) for batched fp32 matrices [B, M, K] x [B, K, N] through the vendor GEMM; `a` / `b` may be
+    transposed or column-sliced VIEWS (the library takes leading dimensions).  Plain fp32: TF32-like modes are refused."""
+    if torch.backends.cuda.matmul.allow_tf32 or torch.get_float32_matmul_precision() != "highest":
+        raise RuntimeError("dvc_amd: the training-side GEMMs need torch's float32 matmul precision 'highest' (no TF32)")
+    for t, name in ((a, "a"), (b, "b")):
+        if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 3:
+            raise RuntimeError(f"dvc_amd: `{name}` must be a float32 ROCm tensor [B, M, K]")
+    if accumulate:
+        if out is None:
+            raise RuntimeError("dvc_amd: accumulate needs `out`")
+        return torch.baddbmm(out, a, b, out=out)
+    return torch.bmm(a, b, out=out) if out is not None else torch.bmm(a, b)
+
+
 # gray2rgb_batch folded into VGG19 conv1_1's load behind warp_color (r06; DVC_GRAY_FUSION=0: the two launches, bit-identical)
 _gray_fusion = _os.environ.get("DVC_GRAY_FUSION", "1") != "0"
 

@@ -440,7 +440,7 @@ int dvc_cx_finish(const float* v, int32_t nb, int32_t n, float* loss, float* gsc
 int dvc_cx_rows_tq(const float* S, int32_t nb, int64_t S_bs, int64_t row_bs, int64_t tq_bs, const float* a, const float* l,
                    const int32_t* cargi, int32_t rows, int32_t N, int32_t row0, float h, float* t, float* q, dvcStream stream);
 /* d loss / d S for a block of rows, row-major (dS, may be NULL) and transposed (dST [nb][N][ld_t], rows >= `rows` zero-filled:
- * the K-major operand of d Xn = Yn dS^T).  mode 0 = ContextualLoss_forward, 1 = ContextualLoss (needs cargi, t, q).
+ * the K-major operand of d Xn = Yn dS^T; may be NULL since r06 when dS is given).  mode 0 = ContextualLoss_forward, 1 = ContextualLoss (needs cargi, t, q).
  * gscale: [nb] device values from dvc_cx_finish (times the upstream gradient of each image's loss); gout: a common factor. */
 int dvc_cx_ds(const float* S, int32_t nb, int64_t S_bs, int64_t row_bs, int64_t tq_bs, const float* a, const float* l, const float* r,
               const float* e, const int32_t* jstar, const int32_t* cargi, const float* t, const float* q, const float* gscale,
@@ -457,7 +457,8 @@ int dvc_cx_normalize_bwd(const float* xn, const float* norm, const float* dxn, i
  * f_blk[rows][P] (= theta_blk^T phi, produced by dvc_conv2d as a 1x1 convolution) into
  *     dS[i][j] = p_ij * (g_i . B_j - g_i . y_i) / T  (+ gsim[i] at j == argmax[i]),   p = softmax_j(f / T)
  * written row-major (dS[rows][P]) and transposed (dST[P][ld_t], rows >= `rows` zero-filled) — the two K-major operands
- * of the 1x1-convolution GEMMs that follow (d phi += theta_blk dS, d theta_blk = phi dS^T).
+ * of the 1x1-convolution GEMMs that follow (d phi += theta_blk dS, d theta_blk = phi dS^T).  dST may be NULL (r06): the
+ * transposed copy is not written — for a caller whose GEMM takes dS transposed as it is (rocBLAS through torch.bmm).
  * gy, y: [3][.] with `chan_stride` elements between channels, already offset to the block's first query; sim, gsim,
  * argmax likewise (gsim / argmax may both be NULL: no gradient through the similarity map).  The softmax is re-evaluated
  * around the row maximum of f_blk ITSELF (the block is recomputed by another GEMM order than the forward kernel's, so the

@@ -39,9 +39,20 @@ def test_contextual_loss_vs_reference_fixtures(golden_dir):
             assert eg < 5e-5, (f, tag, eg)                                             # measured <= 1.7e-6
 
 
+@pytest.fixture(params=["vendor-gemm", "engine-gemm"])
+def gemm_mode(request):
+    """r06: the N x N products run through the vendor's batched GEMM by default (ops.bmm) or on this library's 1x1-convolution
+    engine (DVC_GEMM_LIB=0): both against the same float64 autograd, the same tolerances."""
+    from dvc_amd import ops
+    before = ops.gemm_lib()
+    ops.set_gemm_lib(request.param == "vendor-gemm")
+    yield request.param
+    ops.set_gemm_lib(before)
+
+
 @pytest.mark.parametrize("C,H,W,B,h,centre", [(512, 13, 24, 2, 0.1, True), (512, 27, 48, 1, 0.1, True), (256, 27, 48, 2, 0.1, True),
                                               (64, 24, 40, 1, 0.2, False), (128, 7, 9, 3, 0.1, True)])
-def test_contextual_loss_vs_float64_autograd(C, H, W, B, h, centre):
+def test_contextual_loss_vs_float64_autograd(C, H, W, B, h, centre, gemm_mode):
     X, Y = O.synth_features(1000 + C + H, B, C, H, W)
     gout = torch.linspace(0.5, 1.5, B)
     for tag, (mod, fn) in _mods().items():

@@ -23,8 +23,19 @@ def _inputs(B, h, w, seed):
     return th, ph, lab, gy, gs
 
 
+@pytest.fixture(params=["vendor-gemm", "engine-gemm"])
+def gemm_mode(request):
+    """r06: the backward's three plain GEMMs run through the vendor's batched GEMM by default (ops.bmm) or on this library's
+    1x1-convolution engine (DVC_GEMM_LIB=0): both against the same oracle, the same tolerances."""
+    from dvc_amd import ops
+    before = ops.gemm_lib()
+    ops.set_gemm_lib(request.param == "vendor-gemm")
+    yield request.param
+    ops.set_gemm_lib(before)
+
+
 @pytest.mark.parametrize("h,w,B,T", [(12, 20, 2, 0.01), (10, 16, 2, 0.01), (27, 48, 1, 0.01), (12, 20, 1, 0.005), (9, 7, 2, 0.05)])
-def test_fused_correlation_backward_vs_oracle_autograd(h, w, B, T):
+def test_fused_correlation_backward_vs_oracle_autograd(h, w, B, T, gemm_mode):
     from dvc_amd import ops
     from dvc_amd.corr_autograd import fused_correlation
     from oracle import dvc_oracle as O
@@ -56,7 +67,7 @@ def test_fused_correlation_backward_vs_oracle_autograd(h, w, B, T):
 
 
 @pytest.mark.parametrize("h,w,B,T,scale", [(12, 20, 2, 0.01, 1e-4), (10, 16, 1, 0.01, 0.5), (12, 20, 1, 0.005, 3.0), (27, 48, 1, 0.01, 0.5)])
-def test_fused_correlation_backward_with_wta_scale(h, w, B, T, scale):
+def test_fused_correlation_backward_with_wta_scale(h, w, B, T, scale, gemm_mode):
     """WTA_scale (NonlocalNet.py:288-327, `WTA_scale_weight != 1`), differentiated (r05): float64 autograd through
     oracle.correlate — whose `wta_scale` is the reference's autograd.Function restated, backward constant 1e-4 included,
     pinned bit-exact against the reference class by oracle/pin_reference.py — against the HIP path: forward through the fused
@@ -118,7 +129,7 @@ def _oracle_grads_row_chunked(th, ph, lab, gy, gs, T, rows=1024):
 
 
 @pytest.mark.parametrize("h,w,B,T,autotune", [(54, 96, 2, 0.01, False), (27, 48, 2, 0.01, True), (12, 20, 1, 1e-7, False)])
-def test_fused_correlation_backward_at_the_training_size(h, w, B, T, autotune):
+def test_fused_correlation_backward_at_the_training_size(h, w, B, T, autotune, gemm_mode):
     """The size the training caller runs (train.py:44,402-427: 216x384 crops -> 54 x 96 = 5184 positions, T = 0.01), B = 2:
     11 row blocks of 512 per image (the last one 64 rows) against the row-chunked float64 autograd oracle.
     `autotune=True` repeats a case with ops.set_autotune(True): the d_phi accumulation `conv2d(dS, ..., residual=out, out=out)`
