@@ -17,7 +17,8 @@ bash tools/gpu_check.sh pmcr > gpurun_out/pmcr_stdout.txt 2>&1; echo "pmcr done"
 timeout 200 python tools/corr_roofline_probe.py > gpurun_out/corr_roofline_probe.txt 2>&1; tail -1 gpurun_out/corr_roofline_probe.txt
 rm -rf gpurun_out/corrprof; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/corrprof -o t -- python tools/corr_roofline_probe.py > /dev/null 2>&1
 timeout 300 python tools/refs_chain_probe.py > gpurun_out/refs_chain_probe.txt 2>&1; tail -3 gpurun_out/refs_chain_probe.txt
-timeout 600 python tools/training_side_probe.py > gpurun_out/training_side_probe.txt 2>&1; tail -3 gpurun_out/training_side_probe.txt
+(echo "# default: plain batched GEMMs through the vendor library (ops.bmm)"; timeout 600 python tools/training_side_probe.py; echo; echo "# DVC_GEMM_LIB=0: the same products on the 1x1-convolution engine"; DVC_GEMM_LIB=0 timeout 600 python tools/training_side_probe.py) > gpurun_out/training_side_probe.txt 2>&1; tail -3 gpurun_out/training_side_probe.txt
+timeout 200 python tools/gemm_lib_probe.py > gpurun_out/gemm_lib_probe.txt 2>&1
 find gpurun_out -name "*kernel_trace.csv" -size +6M -delete
 # r05: the tail probe (FGS scan solver), the bf16 bench line's own kernel trace (its roofline block cites it)
 timeout 300 python tools/tail_probe.py > gpurun_out/tail_probe.txt 2>&1; tail -9 gpurun_out/tail_probe.txt

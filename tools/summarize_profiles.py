@@ -35,7 +35,8 @@ for src, dst in (("bench_432x768.json", "bench_line_432x768.json"), ("bench_bf16
                  (os.path.join("prof_bf16", "trace_kernel_stats.csv"), "bench_bf16_kernel_stats.csv"),
                  (os.path.join("corrprof", "t_kernel_stats.csv"), "corr_probe_kernel_stats.csv"),
                  (os.path.join("tailprof", "t_kernel_stats.csv"), "tail_kernel_stats.csv"),
-                 ("tail_insitu_probe.txt", "tail_insitu_probe.txt")):
+                 ("tail_insitu_probe.txt", "tail_insitu_probe.txt"), ("gemm_lib_probe.txt", "gemm_lib_probe.txt"),
+                 ("frame_timeline.txt", "frame_timeline.txt")):
     if os.path.exists(os.path.join(G, src)) and os.path.getmtime(os.path.join(G, src)) > float(os.environ.get("SUMMARIZE_NEWER_THAN", "0")):
         shutil.copy(os.path.join(G, src), os.path.join(P, f"{tag}_{dst}"))
 
