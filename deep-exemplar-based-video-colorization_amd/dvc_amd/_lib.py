@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DVC_DEBUG_LIB=1 (tools/ only) loads the -DDVC_DEBUG build, the only one that carries the dvc_debug_* hooks
 DEBUG_BUILD = os.environ.get("DVC_DEBUG_LIB", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "libdvc_hip_debug.so" if DEBUG_BUILD else "libdvc_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 c_float_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -105,6 +105,7 @@ SIGNATURES = {
     "dvc_lab2rgb_u8": (ctypes.c_int, [_VP, _VP, c_i32, c_i32, _VP, _VP]),
     "dvc_rgb8_to_lab": (ctypes.c_int, [_VP, c_i32, c_i32, _VP, _VP]),
     "dvc_center_pad_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),
+    "dvc_center_pad_is_fused": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
     "dvc_center_pad": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, c_i32, _VP, _VP, ctypes.c_size_t, _VP]),
     "dvc_corr_prepare": (ctypes.c_int, [_VP, c_i32, c_i32, c_i32, ctypes.c_float, _VP, _VP, _VP]),
     "dvc_corr_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32]),

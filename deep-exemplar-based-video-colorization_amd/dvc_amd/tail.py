@@ -92,15 +92,21 @@ def rgb8_to_lab(rgb_hwc):
     return lab
 
 
-def center_pad(rgb_hwc, image_size):
+def center_pad(rgb_hwc, image_size, three_pass=False):
     """CenterPad(image_size)(image) (utils/util_distortion.py:217-258) for an 8-bit H0 x W0 x 3 device image:
-    anti-aliased resize to the target width / height, centre crop -> uint8 [H, W, 3]."""
+    anti-aliased resize to the target width / height, centre crop -> uint8 [H, W, 3].
+    One fused launch where it applies (down-scaling by up to 3.25: r06); `three_pass=True` forces the full-frame passes of
+    r01 (the same bytes; what every other factor runs)."""
     lib = _lib.load()
     if rgb_hwc.dtype != torch.uint8 or not rgb_hwc.is_cuda or not rgb_hwc.is_contiguous() or rgb_hwc.shape[-1] != 3:
         raise RuntimeError("dvc_amd: `rgb` must be a contiguous uint8 ROCm tensor [H, W, 3]")
     H0, W0 = rgb_hwc.shape[:2]
     H, W = int(image_size[0]), int(image_size[1])
     out = torch.empty((H, W, 3), device=rgb_hwc.device, dtype=torch.uint8)
+    if not three_pass and lib.dvc_center_pad_is_fused(H0, W0, H, W):
+        _lib.check(lib.dvc_center_pad(ctypes.c_void_p(rgb_hwc.data_ptr()), H0, W0, H, W, ctypes.c_void_p(out.data_ptr()),
+                                      None, 0, _stream()), "dvc_center_pad")
+        return out
     ws = _workspace(rgb_hwc.device, lib.dvc_center_pad_workspace_bytes(H0, W0), "ingest")
     _lib.check(lib.dvc_center_pad(ctypes.c_void_p(rgb_hwc.data_ptr()), H0, W0, H, W, ctypes.c_void_p(out.data_ptr()),
                                   ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "dvc_center_pad")

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* dvcStream; /* hipStream_t */
 
-#define DVC_ABI_VERSION 18
+#define DVC_ABI_VERSION 19
 
 int dvc_abi_version(void);
 /* Thread-local description of the last failure (empty string if none). */
@@ -349,8 +349,14 @@ int dvc_rgb8_to_lab(const uint8_t* rgb_hwc, int32_t H, int32_t W, float* lab, dv
 /* Frame ingest, geometric half: CenterPad(image_size)(image), utils/util_distortion.py:217-258 — skimage's
  * anti-aliased resize (Gaussian pre-filter + bilinear sampling, mirror boundaries, float64) to the target width or
  * height, centre crop, astype(uint8).  img = [H0][W0][3], out = [H][W][3].  Parity unpinned (skimage absent; the
- * restatement is checked against the SciPy calls skimage makes). */
+ * restatement is checked against the SciPy calls skimage makes).
+ * r06: workspace == NULL selects the FUSED kernel (one launch: a workgroup stages the 8-bit source window of its 8 x 32 output
+ * tile in LDS, every thread filters only the values its bilinear sample reads — same arithmetic in the same order, the same
+ * bytes); it applies when dvc_center_pad_is_fused() says so (down-scaling with a Gaussian radius <= 4 on both axes: factors
+ * up to 3.25; also the same-size copy).  With a workspace of dvc_center_pad_workspace_bytes the three full-frame passes of
+ * r01 run (any factor up to 21). */
 size_t dvc_center_pad_workspace_bytes(int32_t H0, int32_t W0);
+int dvc_center_pad_is_fused(int32_t H0, int32_t W0, int32_t H, int32_t W);
 int dvc_center_pad(const uint8_t* img, int32_t H0, int32_t W0, int32_t H, int32_t W, uint8_t* out, void* workspace,
                    size_t workspace_bytes, dvcStream stream);
 

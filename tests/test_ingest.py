@@ -61,6 +61,30 @@ def test_gpu_center_pad_matches_oracle(src, dst):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("src,dst", [((1080, 1920), (432, 768)), ((480, 640), (216, 384)), ((37, 53), (16, 24)), ((108, 200), (54, 96)),
+                                     ((120, 160), (54, 96)), ((270, 480), (216, 384)), ((90, 250), (54, 96)), ((200, 120), (54, 96)),
+                                     ((720, 1280), (216, 384)), ((433, 770), (216, 384)), ((216, 384), (216, 384)), ((700, 1245), (216, 384)),
+                                     ((30, 40), (54, 96)), ((1000, 1700), (216, 384))])
+def test_gpu_center_pad_fused_kernel_is_the_three_pass_path_byte_for_byte(src, dst):
+    """dvc_center_pad without a workspace (r06): one launch that filters only what the samples read, against the three
+    full-frame float64 passes on the same frame — the same bytes, on every branch of CenterPad (crop rows / crop columns / same
+    ratio / same size), Gaussian radii 0 .. 4, ragged tile edges; factors beyond 3.25 and up-scaling keep the three passes."""
+    from dvc_amd import _lib, tail
+    rng = np.random.default_rng(src[0] + 3 * src[1])
+    yy, xx = np.mgrid[0:src[0], 0:src[1]]
+    img = (127 + 100 * np.sin(yy / 11.0)[..., None] * np.cos(xx / 19.0)[..., None]
+           + rng.normal(0, 25, src + (3,))).clip(0, 255).astype(np.uint8)
+    x = torch.from_numpy(img).cuda()
+    a = tail.center_pad(x, dst)
+    b = tail.center_pad(x, dst, three_pass=True)
+    assert torch.equal(a, b), int((a != b).sum())
+    # which cases the fused kernel takes: the reference's own sizes do; x4.6, up-scaling and unequal radii do not
+    fused = {k: bool(_lib.load().dvc_center_pad_is_fused(*k)) for k in ((1080, 1920, 432, 768), (480, 640, 216, 384), (216, 384, 216, 384),
+                                                                       (1000, 1700, 216, 384), (30, 40, 54, 96), (37, 53, 16, 24))}
+    assert list(fused.values()) == [True, True, True, False, False, False], fused
+
+
+@pytest.mark.gpu
 def test_gpu_center_pad_errors_are_loud():
     from dvc_amd import tail
     img = torch.zeros(64, 64, 3, dtype=torch.uint8)
