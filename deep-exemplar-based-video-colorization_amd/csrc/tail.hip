@@ -853,13 +853,18 @@ __global__ __launch_bounds__(256) void rgb8_to_lab_kernel(const unsigned char* _
     const double M[3][3] = {{0.412453, 0.357580, 0.180423},
                             {0.212671, 0.715160, 0.072169},
                             {0.019334, 0.119193, 0.950227}};
+    // r06: the sRGB -> linear step has 256 possible inputs: every workgroup tabulates it (one float64 pow per thread, the same
+    // expression on the same argument — the same values) instead of evaluating three per pixel; 16.5 -> ~9 us per 432x768 frame
+    __shared__ double lin[256];
+    {
+        const double v = (double)threadIdx.x / 255.0;
+        lin[threadIdx.x] = v > 0.04045 ? pow((v + 0.055) / 1.055, 2.4) : v / 12.92;
+    }
+    __syncthreads();
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
         double c[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double v = (double)rgb[3 * i + k] / 255.0;
-            c[k] = v > 0.04045 ? pow((v + 0.055) / 1.055, 2.4) : v / 12.92;
-        }
+        for (int k = 0; k < 3; ++k) c[k] = lin[rgb[3 * i + k]];
         double xyz[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) xyz[k] = c[0] * M[k][0] + c[1] * M[k][1] + c[2] * M[k][2];
