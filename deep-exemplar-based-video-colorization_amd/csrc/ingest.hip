@@ -107,17 +107,22 @@ __global__ __launch_bounds__(256) void ingest_fused_kernel(const unsigned char* 
     const int wr0 = (int)floor(((double)(oy0 + y_start) + 0.5) * sy - 0.5) - R;
     const int wc0 = (int)floor(((double)(ox0 + x_start) + 0.5) * sx - 0.5) - R;
     // (rows / row slots go to the waves, bytes of a row to the lanes: the row's index arithmetic — the mirror, the float64 sample
-    // coordinate — is wave-uniform; as one flat loop over bytes with a division and two modulos per byte the staging alone took
-    // ~35 us.  The window overshoots the image by at most R + 2 < n: one reflection, no modulo — dvc_center_pad_is_fused demands
-    // H0, W0 >= 16)
+    // coordinate — is wave-uniform, and a lane's source column offsets are the same for every row: computed once.  As one flat
+    // loop over bytes with a division and two modulos per byte the staging alone took ~35 us.  The full mirror rule, not one
+    // reflection: the window of an edge tile reaches up to a tile's width beyond a small image.)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    auto reflect = [](int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); };
+    constexpr int NCB = 6;                                  // 64 * 6 >= the widest window's bytes (host: win_w * 3 <= 384)
+    int coff[NCB];
+#pragma unroll
+    for (int t = 0; t < NCB; ++t) {
+        const int cb = lane + 64 * t, c = cb / 3, ch = cb - 3 * c;
+        coff[t] = cb < wbytes ? mirror_index(wc0 + c, W0) * 3 + ch : -1;
+    }
     for (int r = wave; r < win_h; r += 4) {
-        const unsigned char* src = img + (long)reflect(wr0 + r, H0) * W0 * 3;
-        for (int cb = lane; cb < wbytes; cb += 64) {
-            const int c = cb / 3, ch = cb - 3 * c;
-            win[r * wbytes + cb] = src[reflect(wc0 + c, W0) * 3 + ch];
-        }
+        const unsigned char* src = img + (long)mirror_index(wr0 + r, H0) * W0 * 3;
+#pragma unroll
+        for (int t = 0; t < NCB; ++t)
+            if (coff[t] >= 0) win[r * wbytes + lane + 64 * t] = src[coff[t]];
     }
     __syncthreads();
     // vertical sums: slot s = 2 * (output row of the tile) + (0: the row floor(cy), 1: the row below it)
@@ -215,8 +220,9 @@ static int ingest_win(int tile, double scale, int radius) { return (int)ceil(til
 static size_t ingest_fused_lds(int win_h, int win_w) { return sizeof(double) * 2 * INGEST_TH * win_w * 3 + (size_t)win_h * win_w * 3; }
 
 static bool center_pad_fused_ok(int H0, int W0, int nh, int nw, const GaussTaps& kv, const GaussTaps& kh) {
-    if (nh > H0 || nw > W0 || kv.radius != kh.radius || kv.radius > 4 || H0 < 16 || W0 < 16) return false;
-    return ingest_fused_lds(ingest_win(INGEST_TH, (double)H0 / nh, kv.radius), ingest_win(INGEST_TW, (double)W0 / nw, kv.radius)) <= 64 * 1024;
+    if (nh > H0 || nw > W0 || kv.radius != kh.radius || kv.radius > 4) return false;
+    const int win_w = ingest_win(INGEST_TW, (double)W0 / nw, kv.radius);
+    return win_w * 3 <= 384 && ingest_fused_lds(ingest_win(INGEST_TH, (double)H0 / nh, kv.radius), win_w) <= 64 * 1024;
 }
 
 extern "C" int dvc_center_pad_is_fused(int32_t H0, int32_t W0, int32_t H, int32_t W) {

@@ -64,7 +64,8 @@ def test_gpu_center_pad_matches_oracle(src, dst):
 @pytest.mark.parametrize("src,dst", [((1080, 1920), (432, 768)), ((480, 640), (216, 384)), ((37, 53), (16, 24)), ((108, 200), (54, 96)),
                                      ((120, 160), (54, 96)), ((270, 480), (216, 384)), ((90, 250), (54, 96)), ((200, 120), (54, 96)),
                                      ((720, 1280), (216, 384)), ((433, 770), (216, 384)), ((216, 384), (216, 384)), ((700, 1245), (216, 384)),
-                                     ((30, 40), (54, 96)), ((1000, 1700), (216, 384))])
+                                     ((30, 40), (54, 96)), ((1000, 1700), (216, 384)), ((100, 150), (40, 60)), ((20, 30), (8, 12)), ((65, 97), (26, 39)),
+                                     ((17, 300), (16, 282))])
 def test_gpu_center_pad_fused_kernel_is_the_three_pass_path_byte_for_byte(src, dst):
     """dvc_center_pad without a workspace (r06): one launch that filters only what the samples read, against the three
     full-frame float64 passes on the same frame — the same bytes, on every branch of CenterPad (crop rows / crop columns / same
