@@ -137,8 +137,12 @@ class _ContextualCX(torch.autograd.Function):
                 _lib.check(lib.dvc_cx_ds(_p(S), B, S_bs, Nx, R, _p(a[:, sl]), _p(l[:, sl]), _p(r[:, sl]), _p(e[:, sl]), _ip(jstar[:, sl]),
                                          None if cargi is None else _ip(cargi), _p(tt), _p(qq), _p(gs), 1.0, mode, rows, Ny, i0, rows, h,
                                          _p(dS), None, st), "dvc_cx_ds")
-                ops.bmm(Yn, dS.transpose(1, 2), out=dxb)                      # d Xn[b, c, i0 + i] = sum_j Yn[b, c, j] dS[b, i, j]
-                dXn[:, :, i0:i0 + rows] = dxb
+                # d Xn[b, c, i0 + i] = sum_j Yn[b, c, j] dS[b, i, j]   (one block for all rows: straight into dXn, no copy)
+                if rows == Nx:
+                    ops.bmm(Yn, dS.transpose(1, 2), out=dXn)
+                else:
+                    ops.bmm(Yn, dS.transpose(1, 2), out=dxb)
+                    dXn[:, :, i0:i0 + rows] = dxb
             dX = torch.empty_like(Xn)
             _lib.check(lib.dvc_cx_normalize_bwd(_p(Xn), _p(normX), _p(dXn), B, C, Nx, float(EPS64), _p(dX), st), "dvc_cx_normalize_bwd")
             return dX.view(xshape), None, None, None, None
