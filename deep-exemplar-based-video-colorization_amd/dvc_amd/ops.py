@@ -620,7 +620,8 @@ def bmm(a, b, out=None, accumulate=False):
     """out = a @ b (or out += a @ b) for batched fp32 matrices [B, M, K] x [B, K, N] through the vendor GEMM; `a` / `b` may be
     transposed or column-sliced VIEWS (the library takes leading dimensions).  Plain fp32: TF32-like modes are refused."""
     if torch.backends.cuda.matmul.allow_tf32 or torch.get_float32_matmul_precision() != "highest":
-        raise RuntimeError("dvc_amd: the training-side GEMMs need torch's float32 matmul precision 'highest' (no TF32)")
+        raise RuntimeError("dvc_amd: the training-side GEMMs need torch's float32 matmul precision 'highest' (no TF32); "
+                           "restore it, or set DVC_GEMM_LIB=0 to keep these products on this library's own fp32 engine")
     for t, name in ((a, "a"), (b, "b")):
         if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 3:
             raise RuntimeError(f"dvc_amd: `{name}` must be a float32 ROCm tensor [B, M, K]")

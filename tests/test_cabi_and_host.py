@@ -373,3 +373,20 @@ def test_exemplar_memo_keys_on_identity_versions_and_weights():
     finally:
         ops.set_exemplar_memo(True)
     assert ops.exemplar_memo_mode() == "on"
+
+
+def test_training_side_gemm_guard_refuses_reduced_precision_and_cpu_tensors():
+    """ops.bmm (r06: the training side's plain batched GEMMs on the vendor library) computes in plain fp32 or not at all: a
+    relaxed float32 matmul precision raises (with the way out in the message), and so do CPU tensors — no silent fallback."""
+    import torch
+    from dvc_amd import ops
+    before = torch.get_float32_matmul_precision()
+    try:
+        torch.set_float32_matmul_precision("high")
+        with pytest.raises(RuntimeError, match="DVC_GEMM_LIB=0"):
+            ops.bmm(torch.zeros(1, 2, 2), torch.zeros(1, 2, 2))
+    finally:
+        torch.set_float32_matmul_precision(before)
+    with pytest.raises(RuntimeError, match="ROCm tensor"):
+        ops.bmm(torch.zeros(1, 2, 2), torch.zeros(1, 2, 2))
+    assert ops.gemm_lib() in (True, False)
